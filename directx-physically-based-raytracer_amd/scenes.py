@@ -1,0 +1,380 @@
+"""Procedural scenes in the reference's Mesh / MeshNode / ObjectData / InstanceData layout.
+
+The reference's Cornell Box asset (Assets/Scenes/Default.json, Source/App.cpp:129-131) is not in
+its tree, so the BASELINE.json configs are generated here (SURVEY.md 8d "Synthetic inputs"):
+  cornell_box()      C1 / C2 / C4   (~36-60 triangles, 8-9 mesh-node instances)
+  sponza_scale()     C3             (~250k triangles, one BLAS, 24 materials)
+  instanced_grid()   C5             (10k instances of one mesh, two-level BVH)
+What the host does with them mirrors Scene::Refresh (Source/Scene.ixx:195-231: InstanceData,
+FirstGeometryIndex) and App::UpdateScene (Source/App.cpp:1016-1074: ObjectData fill).
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import layouts as L
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side encoders (Source/Vertex.ixx:17-26; MathLib float2_to_snorm_16_16 / float2_to_float16_t2)
+# ----------------------------------------------------------------------------------------------
+def encode_snorm16(v):
+    v = np.clip(np.asarray(v, np.float64), -1.0, 1.0) * 32767.0
+    return np.where(v >= 0, np.floor(v + 0.5), np.ceil(v - 0.5)).astype(np.int16)
+
+
+def make_vertices(positions, normals=None, uvs=None):
+    vb = np.zeros(len(positions), L.VERTEX)
+    vb["Position"] = np.asarray(positions, np.float32)
+    if normals is not None:
+        vb["Normal"] = encode_snorm16(normals)
+    if uvs is not None:
+        vb["TexCoord0"] = np.asarray(uvs, np.float16)
+    return vb
+
+
+def make_indices(idx):
+    """u16 if index count <= 65535 else u32 (Source/GLTFHelpers.ixx:183-188)."""
+    idx = np.asarray(idx).reshape(-1)
+    return idx.astype(np.uint16 if idx.size <= 65535 else np.uint32)
+
+
+@dataclass
+class Mesh:                      # Source/Model.ixx:26-47
+    vertices: np.ndarray         # L.VERTEX
+    indices: np.ndarray          # uint16 / uint32
+    has_normals: bool = True
+    material: np.ndarray = None  # L.MATERIAL scalar, None => Material() (App.cpp:1044)
+
+
+@dataclass
+class MeshNode:                  # Source/Model.ixx:58-70: one BLAS per mesh node
+    meshes: list
+
+
+@dataclass
+class RenderObject:              # one instance of a mesh node with its world transform (3x4, column-vector [R|t])
+    node: int
+    transform: np.ndarray
+    visible: bool = True
+
+
+def trs(translation=(0, 0, 0), yaw_deg=0.0, scale=(1, 1, 1), pitch_deg=0.0):
+    """3x4 object-to-world = T * R_y(yaw) * R_x(pitch) * S (column-vector convention)."""
+    cy, sy = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    cp, sp = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    m = np.zeros((3, 4))
+    m[:, :3] = ry @ rx @ np.diag(scale)
+    m[:, 3] = translation
+    return m.astype(np.float32)
+
+
+@dataclass
+class Scene:
+    nodes: list
+    objects: list
+    camera: np.ndarray = None
+    scene_data: np.ndarray = None
+    name: str = "scene"
+    # flattened, filled by finalize()
+    heap: list = field(default_factory=list)          # list of (np.ndarray bytes-owner, stride)
+    geometry: list = field(default_factory=list)      # per BLAS geometry: (mesh, heap_v, heap_i)
+    blas: list = field(default_factory=list)          # (first_geometry, geometry_count) per node
+    object_data: np.ndarray = None
+    instance_data: np.ndarray = None
+    instance_ids: np.ndarray = None
+    instance_masks: np.ndarray = None
+    instance_blas: np.ndarray = None
+
+    def finalize(self):
+        """Scene::Refresh + App::UpdateScene: InstanceData / ObjectData / descriptor heap."""
+        self.heap, self.geometry, self.blas = [], [], []
+        mesh_heap = {}
+        for node in self.nodes:
+            first = len(self.geometry)
+            for mesh in node.meshes:
+                key = id(mesh)
+                if key not in mesh_heap:
+                    hv = len(self.heap); self.heap.append((mesh.vertices, 0))
+                    hi = len(self.heap); self.heap.append((mesh.indices, mesh.indices.dtype.itemsize))
+                    mesh_heap[key] = (hv, hi)
+                self.geometry.append((mesh,) + mesh_heap[key])
+            self.blas.append((first, len(node.meshes)))
+        n_inst = len(self.objects)
+        self.instance_data = np.zeros(n_inst, L.INSTANCE_DATA)
+        self.instance_ids = np.zeros(n_inst, np.uint32)
+        self.instance_masks = np.zeros(n_inst, np.uint32)
+        self.instance_blas = np.zeros(n_inst, np.uint32)
+        objs = []
+        object_index = 0
+        for i, ro in enumerate(self.objects):
+            node = self.nodes[ro.node]
+            self.instance_data[i]["FirstGeometryIndex"] = object_index
+            self.instance_data[i]["PreviousObjectToWorld"] = ro.transform
+            self.instance_data[i]["ObjectToWorld"] = ro.transform
+            self.instance_ids[i] = object_index          # InstanceID = FirstGeometryIndex (Scene.ixx:371)
+            self.instance_masks[i] = 0xFF if ro.visible else 0
+            self.instance_blas[i] = ro.node
+            first, count = self.blas[ro.node]
+            for g in range(count):
+                mesh, hv, hi = self.geometry[first + g]
+                od = np.zeros((), L.OBJECT_DATA)
+                od["VertexDesc"]["Stride"] = L.VERTEX.itemsize
+                od["VertexDesc"]["Normal"] = 12 if mesh.has_normals else L.NONE
+                od["VertexDesc"]["Tangent"] = L.NONE
+                od["VertexDesc"]["TexCoord"] = (L.NONE, L.NONE)
+                od["MeshDescriptors"]["Vertices"] = hv
+                od["MeshDescriptors"]["Indices"] = hi
+                od["MeshDescriptors"]["MotionVectors"] = L.NONE
+                od["Material"] = mesh.material if mesh.material is not None else L.default_material()
+                od["TextureMapInfoArray"]["Descriptor"] = L.NONE
+                objs.append(od)
+            object_index += count
+        self.object_data = np.array(objs, L.OBJECT_DATA) if objs else np.zeros(0, L.OBJECT_DATA)
+        return self
+
+    @property
+    def triangle_count(self):
+        return sum(sum(m.indices.size // 3 for m in self.nodes[o.node].meshes) for o in self.objects)
+
+
+# ----------------------------------------------------------------------------------------------
+# camera (Source/Camera.ixx:38-177 CameraController, Source/App.cpp:540-561)
+# ----------------------------------------------------------------------------------------------
+def make_camera(position, forward=(0, 0, 1), up=(0, 1, 0), hfov_deg=90.0, aspect=16 / 9,
+                near=0.01, far=float("inf"), jitter=(0.0, 0.0)):
+    pos = np.asarray(position, np.float64)
+    f = np.asarray(forward, np.float64); f /= np.linalg.norm(f)
+    r = np.cross(np.asarray(up, np.float64), f); r /= np.linalg.norm(r)   # Right = up x forward (LH)
+    u = np.cross(f, r)                                                      # Up = forward x right
+    right_len = math.tan(math.radians(hfov_deg) / 2)                        # |Forward| = focus distance = 1
+    up_len = right_len / aspect
+    cam = np.zeros((), L.CAMERA)
+    cam["IsNormalizedDepthReversed"] = 1
+    cam["PreviousPosition"] = cam["Position"] = pos
+    cam["RightDirection"] = r * right_len
+    cam["UpDirection"] = u * up_len
+    cam["ForwardDirection"] = f
+    cam["NearDepth"], cam["FarDepth"] = near, far
+    cam["Jitter"] = jitter
+    # XMMatrixLookToLH, row-vector convention
+    w2v = np.eye(4)
+    w2v[:3, 0], w2v[:3, 1], w2v[:3, 2] = r, u, f
+    w2v[3, :3] = [-pos @ r, -pos @ u, -pos @ f]
+    # [MathLib spec] float4x4::SetupByHalfFovxInf, LH reversed-Z infinite far plane
+    v2p = np.zeros((4, 4))
+    v2p[0, 0] = 1 / right_len
+    v2p[1, 1] = aspect / right_len
+    v2p[2, 3] = 1
+    v2p[3, 2] = near
+    if math.isfinite(far):   # SetupByHalfFovx, reversed Z
+        v2p[2, 2] = -near / (far - near)
+        v2p[3, 2] = far * near / (far - near)
+    v2w = np.eye(4)
+    v2w[0, :3], v2w[1, :3], v2w[2, :3], v2w[3, :3] = r, u, f, pos
+    w2p = w2v @ v2p
+    p2v = np.linalg.inv(v2p)
+    for prefix in ("Previous", ""):
+        cam[prefix + "WorldToProjection"] = w2p
+        cam[prefix + "ProjectionToView"] = p2v
+        cam[prefix + "ViewToWorld"] = v2w
+    cam["PreviousWorldToView"] = w2v
+    cam["PreviousViewToProjection"] = v2p
+    return cam
+
+
+def make_scene_data(env_color=(0, 0, 0, 1), is_static=True):
+    """EnvironmentLightColor.a < 0 selects the procedural sky (Scene.ixx:58 default (0,0,0,-1))."""
+    sd = np.zeros((), L.SCENE_DATA)
+    sd["IsStatic"] = 1 if is_static else 0
+    sd["EnvironmentLightTextureDescriptor"] = L.NONE
+    sd["EnvironmentLightColor"] = env_color
+    sd["EnvironmentLightTransform"] = np.eye(3, 4)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# mesh builders
+# ----------------------------------------------------------------------------------------------
+def material(base=(0.73, 0.73, 0.73), emissive=(0, 0, 0), strength=1.0, metallic=0.0, roughness=0.5,
+             ior=1.5, transmission=0.0):
+    m = L.default_material()
+    m["BaseColor"] = tuple(base) + (1.0,)
+    m["EmissiveColor"] = emissive
+    m["EmissiveStrength"] = strength
+    m["Metallic"], m["Roughness"], m["IOR"], m["Transmission"] = metallic, roughness, ior, transmission
+    return m
+
+
+def quad_mesh(p0, p1, p2, p3, normal, mat, has_normals=True):
+    """Two triangles (p0,p1,p2), (p0,p2,p3)."""
+    pos = np.array([p0, p1, p2, p3], np.float32)
+    nrm = np.tile(np.asarray(normal, np.float32), (4, 1))
+    return Mesh(make_vertices(pos, nrm), make_indices([0, 1, 2, 0, 2, 3]), has_normals, mat)
+
+
+def box_mesh(mat, has_normals=True):
+    """Unit cube [-0.5,0.5]^3, 24 vertices with per-face normals, 12 triangles."""
+    pos, nrm, idx = [], [], []
+    for axis in range(3):
+        for sgn in (-1.0, 1.0):
+            n = np.zeros(3); n[axis] = sgn
+            a, b = (axis + 1) % 3, (axis + 2) % 3
+            corners = []
+            for sa, sb in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+                p = np.zeros(3); p[axis] = 0.5 * sgn; p[a] = 0.5 * sa; p[b] = 0.5 * sb
+                corners.append(p)
+            if sgn < 0:
+                corners = corners[::-1]
+            base = len(pos)
+            pos += corners; nrm += [n] * 4
+            idx += [base, base + 1, base + 2, base, base + 2, base + 3]
+    return Mesh(make_vertices(np.array(pos), np.array(nrm)), make_indices(idx), has_normals, mat)
+
+
+def icosphere_mesh(subdiv, mat):
+    """Smooth-normal unit sphere (radius 1)."""
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2),
+         (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11),
+         (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]; v.append(m / np.linalg.norm(m)); cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    pos = np.array(v)
+    return Mesh(make_vertices(pos, pos), make_indices(np.array(f).reshape(-1)), True, mat)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json scenes
+# ----------------------------------------------------------------------------------------------
+def cornell_box(aspect=16 / 9, variant="ggx", glass_sphere=False, has_normals=True, jitter=(0.0, 0.0)):
+    """Cornell Box, LH, +Z forward, box = [-1,1]^3 open at z=-1, camera in front of the opening.
+
+    variant "diffuse": every surface uses the reference's default Roughness 0.5 / Metallic 0 / IOR 1.5.
+    variant "ggx" (config C2 "full GGX metallic-roughness"): tall box Metallic 1 Roughness 0.05,
+    short box Roughness 0.2. glass_sphere adds a Transmission 1 sphere (exercises the third lobe).
+    """
+    white, red, green = (0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)
+    hn = has_normals
+    nodes = [
+        MeshNode([quad_mesh((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1), (0, 1, 0), material(white), hn)]),   # floor
+        MeshNode([quad_mesh((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0), material(white), hn)]),      # ceiling
+        MeshNode([quad_mesh((-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1), (0, 0, -1), material(white), hn)]),      # back
+        MeshNode([quad_mesh((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1), (1, 0, 0), material(red), hn)]),     # left
+        MeshNode([quad_mesh((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0), material(green), hn)]),      # right
+        MeshNode([quad_mesh((-0.25, 0, -0.25), (0.25, 0, -0.25), (0.25, 0, 0.25), (-0.25, 0, 0.25), (0, -1, 0),
+                            material((0.78, 0.78, 0.78), emissive=(1, 1, 1), strength=15.0), hn)]),                # light
+    ]
+    if variant == "ggx":
+        tall = material((0.95, 0.93, 0.88), metallic=1.0, roughness=0.05)
+        short = material(white, roughness=0.2)
+    else:
+        tall, short = material(white), material(white)
+    nodes.append(MeshNode([box_mesh(tall, hn)]))
+    nodes.append(MeshNode([box_mesh(short, hn)]))
+    ident = trs()
+    objects = [RenderObject(i, ident) for i in range(5)]
+    objects.append(RenderObject(5, trs((0, 0.998, 0.1))))
+    objects.append(RenderObject(6, trs((-0.35, -0.4, 0.35), -18.0, (0.6, 1.2, 0.6))))
+    objects.append(RenderObject(7, trs((0.35, -0.7, -0.25), 15.0, (0.6, 0.6, 0.6))))
+    if glass_sphere:
+        nodes.append(MeshNode([icosphere_mesh(2, material((0.98, 0.98, 1.0), roughness=0.05, transmission=1.0))]))
+        objects.append(RenderObject(8, trs((0.35, -0.15, -0.25), 0.0, (0.25, 0.25, 0.25))))
+    cam = make_camera((0, 0, -1.95), hfov_deg=90.0, aspect=aspect, jitter=jitter)
+    return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, 1)), name="cornell_" + variant).finalize()
+
+
+def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24):
+    """~250k-triangle displaced terrain + column grid in ONE BLAS (config C3); materials vary per strip."""
+    rng = np.random.default_rng(seed)
+    strips = n_materials
+    rows_per = max(1, n_side // strips)
+    meshes = []
+    xs = np.linspace(-4, 4, n_side + 1)
+    zs = np.linspace(-1, 9, n_side + 1)
+    gx, gz = np.meshgrid(xs, zs, indexing="xy")
+    h = (0.15 * np.sin(gx * 2.1) * np.cos(gz * 1.7) + 0.05 * rng.standard_normal(gx.shape)).astype(np.float64)
+    # arcade: raise two side walls and periodic columns
+    h += 2.5 * (np.abs(gx) > 3.2)
+    h += 1.8 * ((np.abs(np.abs(gx) - 2.0) < 0.12) & (np.mod(gz, 1.0) < 0.24))
+    h -= 1.0
+    r0 = 0
+    for s in range(strips):
+        r1 = n_side if s == strips - 1 else r0 + rows_per
+        if r1 <= r0:
+            break
+        sub = np.s_[r0:r1 + 1, :]
+        px, pz, py = gx[sub], gz[sub], h[sub]
+        pos = np.stack([px, py, pz], -1).reshape(-1, 3)
+        # normals from central differences
+        dy_dx = np.gradient(h, xs, axis=1)[sub]; dy_dz = np.gradient(h, zs, axis=0)[sub]
+        nrm = np.stack([-dy_dx, np.ones_like(dy_dx), -dy_dz], -1).reshape(-1, 3)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        nr, nc = r1 - r0 + 1, n_side + 1
+        i0 = (np.arange(nr - 1)[:, None] * nc + np.arange(nc - 1)[None, :]).reshape(-1)
+        idx = np.stack([i0, i0 + nc, i0 + 1, i0 + 1, i0 + nc, i0 + nc + 1], -1).reshape(-1)
+        col = tuple(0.25 + 0.6 * rng.random(3))
+        mat = material(col, metallic=float(s % 5 == 0), roughness=float(0.08 + 0.8 * rng.random()))
+        meshes.append(Mesh(make_vertices(pos, nrm), make_indices(idx), True, mat))
+        r0 = r1
+    light = quad_mesh((-1.5, 0, -1.5), (1.5, 0, -1.5), (1.5, 0, 1.5), (-1.5, 0, 1.5), (0, -1, 0),
+                      material((0.8, 0.8, 0.8), emissive=(1, 0.95, 0.9), strength=20.0))
+    nodes = [MeshNode(meshes), MeshNode([light])]
+    objects = [RenderObject(0, trs()), RenderObject(1, trs((0, 3.0, 4.0)))]
+    cam = make_camera((0, 0.4, -0.5), forward=(0, -0.12, 1), hfov_deg=90.0, aspect=aspect)
+    return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, -1)), name="sponza_scale").finalize()
+
+
+def instanced_grid(n=100, seed=42, aspect=16 / 9, subdiv=2):
+    """n*n instances of one icosphere-derived mesh on a jittered grid + ground + light (config C5)."""
+    rng = np.random.default_rng(seed)
+    blob = icosphere_mesh(subdiv, material((0.8, 0.6, 0.3), metallic=1.0, roughness=0.25))
+    ground = quad_mesh((-1, 0, -1), (-1, 0, 1), (1, 0, 1), (1, 0, -1), (0, 1, 0), material((0.6, 0.6, 0.6)))
+    light = quad_mesh((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, -1, 0),
+                      material((0.8, 0.8, 0.8), emissive=(1, 1, 1), strength=12.0))
+    nodes = [MeshNode([blob]), MeshNode([ground]), MeshNode([light])]
+    objects = []
+    span = 20.0
+    for iz in range(n):
+        for ix in range(n):
+            x = (ix + 0.5) / n * span - span / 2 + (rng.random() - 0.5) * 0.08
+            z = (iz + 0.5) / n * span + (rng.random() - 0.5) * 0.08
+            s = 0.04 + 0.04 * rng.random()
+            objects.append(RenderObject(0, trs((x, s * 0.9, z), rng.random() * 360.0, (s, s * (0.7 + 0.6 * rng.random()), s),
+                                                pitch_deg=rng.random() * 40 - 20)))
+    objects.append(RenderObject(1, trs((0, 0, span / 2), 0, (span, 1, span))))
+    objects.append(RenderObject(2, trs((0, 6.0, span / 2), 0, (4, 1, 4))))
+    cam = make_camera((0, 1.2, -0.5), forward=(0, -0.25, 1), hfov_deg=90.0, aspect=aspect)
+    return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, -1)), name="instanced_grid").finalize()
+
+
+def graphics_settings(width, height, spp=1, bounces=8, frame_index=0, russian_roulette=True, ext_flags=0,
+                      throughput_threshold=1e-3):
+    """Raytracing::GraphicsSettings with the reference defaults (MyAppData.h:182-188, Raytracing.ixx:33)."""
+    gs = np.zeros((), L.GRAPHICS_SETTINGS)
+    gs["RenderSize"] = (width, height)
+    gs["FrameIndex"], gs["Bounces"], gs["SamplesPerPixel"] = frame_index, bounces, spp
+    gs["ThroughputThreshold"] = throughput_threshold
+    gs["IsRussianRouletteEnabled"] = 1 if russian_roulette else 0
+    gs["ExtFlags"] = ext_flags
+    return gs
+
+
+def alloc_gbuffer(width, height):
+    """Host G-buffer in the reference's texture formats (Source/App.cpp:438-455)."""
+    return {k: np.zeros((height, width, c), dt) for k, (dt, c) in L.GBUFFER_FORMATS.items()}
