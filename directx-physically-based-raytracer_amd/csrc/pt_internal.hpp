@@ -1,0 +1,99 @@
+// pt_internal.hpp -- host-side context and the internal interfaces between the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ptamd.h"
+#include "pt_trace.hpp"
+
+namespace pt {
+
+constexpr uint32_t kLeafTris = 4;            // triangles per BLAS leaf (count field is 3 bits: <= 8)
+
+struct Blas {
+    BvhNode* nodes = nullptr;
+    TriPacket* tris = nullptr;
+    float* rootBounds = nullptr;             // device: lo.xyz hi.xyz
+    uint32_t triCount = 0, leafCount = 0, nodeCount = 0;
+};
+
+struct Tlas {
+    BvhNode* nodes = nullptr;
+    InstanceRecord* instances = nullptr;     // device, indexed by InstanceIndex
+    uint32_t instanceCount = 0, nodeCount = 0;
+    uint64_t triangleCount = 0;              // sum over instances
+};
+
+struct HeapEntry { const void* ptr; uint64_t bytes; uint32_t stride; uint32_t _pad; };   // device copy is the same struct
+
+// everything a render kernel needs about the scene, passed by value as a kernel argument
+struct SceneView {
+    AccelView accel;
+    const PtObjectData* objects;
+    const PtInstanceData* instanceData;
+    const HeapEntry* heap;
+    uint32_t objectCount, heapCount;
+};
+
+struct FrameView {                           // G-buffer geometry of this context's shard
+    uint32_t width, height;                  // full frame
+    uint32_t localRows;                      // rows held by this rank
+    uint32_t rankIndex, rankCount, bandHeight;
+};
+
+// wavefront path state, structure of arrays, 16-byte records (DESIGN.md "Queues")
+struct PathQueue {
+    float4* s0;      // throughput.xyz | pixel (local index, bits)
+    float4* s1;      // sampleRadiance.xyz | rng state (bits)
+    float4* s2;      // radiance sum.xyz | sample << 16 | bounce << 1 | fresh (bits)
+    float4* r0;      // ray origin.xyz | tmin
+    float4* r1;      // ray direction.xyz | tmax
+    uint4*  hit;     // instance | triangle slot in the BLAS | u bits | v bits      (instance ~0u = miss)
+};
+
+struct DeviceCounters {
+    unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string lastError;
+
+    std::vector<HeapEntry> heapHost;
+    HeapEntry* heapDev = nullptr; uint32_t heapDevCap = 0; bool heapDirty = true;
+
+    std::map<uint64_t, Blas> blas; uint64_t nextBlasId = 1;
+    Tlas tlas; bool haveTlas = false;
+
+    PtCamera camera{}; PtSceneData sceneData{}; PtGraphicsSettings settings{};
+    bool haveCamera = false, haveSceneData = false, haveSettings = false;
+    const PtObjectData* objects = nullptr; uint32_t objectCount = 0;
+    const PtInstanceData* instanceData = nullptr; uint32_t instanceDataCount = 0;
+    PtSharding sharding{0, 1, 16, 0};
+
+    PathQueue queue[2]{}; uint32_t queueCapacity = 0;
+    uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;
+    DeviceCounters* counters = nullptr;
+    uint64_t lastIterations = 0;
+    uint32_t debugFlags = 0;
+
+    bool timing = false;
+    std::vector<hipEvent_t> evExtend, evShade;     // begin/end pairs of the last frame
+    uint32_t nExtend = 0, nShade = 0;
+};
+
+// pt_bvh.hip
+hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& out);
+hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out);
+
+// pt_kernels.hip
+hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);
+hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx);
+hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsDev, uint32_t rankCount,
+                               uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
+
+} // namespace pt

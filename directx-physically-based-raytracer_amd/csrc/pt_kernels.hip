@@ -1,0 +1,457 @@
+// pt_kernels.hip -- the render kernels (gfx950): primary-ray G-buffer and the wavefront path tracer.
+//
+//   k_gbuffer   <- Shaders/GBufferGeneration.hlsl:116-232 (main) + CastRay, Shaders/RaytracingHelpers.hlsli:57-133
+//   k_pt_init / k_shade / k_extend  <- Shaders/Raytracing.hlsl:103-415 (RayGeneration, DEFAULT permutation,
+//                                      Denoiser::None, DI off), split into wavefront stages:
+//        shade   : material + BSDF sample + Russian roulette for the vertex a path sits on
+//                  (Raytracing.hlsl:241-364), emits the next ray, regenerates the pixel's next sample in
+//                  place when a path ends (RNG state carried over, Raytracing.hlsl:108,191), compacts the
+//                  survivors with wave64 ballot + prefix popcount into the output queue
+//        extend  : closest-hit traversal of every queued ray (CastRay's TraceRay part)
+// MFMA is not used: there is no dense contraction on this path.
+#include "pt_internal.hpp"
+
+namespace pt {
+
+// ---------------------------------------------------------------------------------------------
+// shared device helpers
+// ---------------------------------------------------------------------------------------------
+struct RayDesc { v3 o, d; float tmin, tmax; };
+
+// Camera::GeneratePinholeRay (Shaders/Camera.hlsli:27-41), Math::CalculateUV/NDC (Shaders/Math.hlsli:7-15)
+PT_DEV RayDesc generate_pinhole_ray(const PtCamera& cam, uint32_t px, uint32_t py, uint32_t W, uint32_t H, float& u, float& v)
+{
+    u = ((float)px + 0.5f + cam.Jitter[0]) / (float)W;
+    v = ((float)py + 0.5f + cam.Jitter[1]) / (float)H;
+    float nx = u * 2.0f + -1.0f, ny = v * -2.0f + 1.0f;
+    v3 R = V3(cam.RightDirection), U = V3(cam.UpDirection), F = V3(cam.ForwardDirection);
+    v3 d = V3(nx * R.x + ny * U.x + F.x, nx * R.y + ny * U.y + F.y, nx * R.z + ny * U.z + F.z);
+    RayDesc r;
+    r.o = V3(cam.Position);
+    r.d = normalize(d);
+    float invCos = 1.0f / dot(normalize(F), r.d);
+    r.tmin = cam.NearDepth * invCos;
+    r.tmax = cam.FarDepth * invCos;
+    return r;
+}
+
+PT_DEV uint32_t global_row(const FrameView& fv, uint32_t localRow)
+{
+    uint32_t band = localRow / fv.bandHeight, within = localRow - band * fv.bandHeight;
+    return (band * fv.rankCount + fv.rankIndex) * fv.bandHeight + within;
+}
+
+// GetEnvironmentLightColor (Shaders/ShadingHelpers.hlsli:11-30); environment textures are "next" 
+PT_DEV v3 environment_light_color(const PtSceneData& sd, v3 dir)
+{
+    if (sd.EnvironmentLightColor[3] >= 0.0f) return V3(sd.EnvironmentLightColor);
+    float t = (dir.y + 1.0f) * 0.5f;
+    return V3(ml_from_srgb1(1.0f + t * (0.5f - 1.0f)), ml_from_srgb1(1.0f + t * (0.7f - 1.0f)), ml_from_srgb1(1.0f + t * (1.0f - 1.0f)));
+}
+
+// row-vector transform by an XMFLOAT4X4 (HLSL mul(M, float4(p,1)) on the column-major view of it)
+PT_DEV void xform4(const float* M, v3 p, float out[4])
+{
+    for (int j = 0; j < 4; j++) out[j] = p.x * M[j] + p.y * M[4 + j] + p.z * M[8 + j] + M[12 + j];
+}
+
+struct SurfaceHit {               // the part of HitInfo (Shaders/HitInfo.hlsli:7-22) this path consumes
+    v3 Position, ObjectPosition; float PositionOffset;
+    v3 FlatNormal, GeometricNormal, ShadingNormal;
+    bool IsFrontFace;
+    uint32_t InstanceIndex, ObjectIndex, PrimitiveIndex;
+};
+
+PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)      // MeshHelpers.hlsli:5-9 (typed R16/R32 buffer)
+{
+    return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
+}
+
+// Hit reconstruction half of CastRay (Shaders/RaytracingHelpers.hlsli:73-131) + HitInfo::Initialize
+// (Shaders/HitInfo.hlsli:24-65). Positions come from the BLAS triangle packet (bit-identical copies of the
+// vertex-buffer positions); normals from the vertex buffer through the descriptor heap.
+PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot, float bu, float bv, v3 rayDir, SurfaceHit& h)
+{
+    const InstanceRecord* ir = &sv.accel.instances[inst];
+    const TriPacket tp = ir->tris[triSlot];
+    const uint32_t geom = __float_as_uint(tp.a.w), prim = __float_as_uint(tp.b.w);
+    h.InstanceIndex = inst;
+    h.ObjectIndex = ir->instanceID + geom;                 // RaytracingHelpers.hlsli:79
+    h.PrimitiveIndex = prim;
+    float M[12], W[12];
+    #pragma unroll
+    for (int k = 0; k < 12; k++) { M[k] = ir->objectToWorld[k]; W[k] = ir->worldToObject[k]; }
+    safe_triangle_spawn_point(V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), bu, bv, M, W,
+                              h.ObjectPosition, h.Position, h.FlatNormal, h.PositionOffset);
+    const PtObjectData* od = &sv.objects[h.ObjectIndex];
+    const uint32_t nOff = od->VertexDesc.AttributeOffsets.Normal;
+    if (nOff != ~0u) {                                     // HitInfo.hlsli:52-65
+        const HeapEntry vb = sv.heap[od->MeshDescriptors.Vertices], ib = sv.heap[od->MeshDescriptors.Indices];
+        const uint32_t stride = od->VertexDesc.Stride;
+        v3 nrm[3];
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
+            const int16_t* q = (const int16_t*)((const uint8_t*)vb.ptr + (size_t)stride * idx + nOff);
+            nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
+        }
+        v3 n = (nrm[0] + (nrm[1] - nrm[0]) * bu) + (nrm[2] - nrm[0]) * bv;          // Vertex::Interpolate, Vertex.hlsli:63-72
+        v3 g = V3(W[0] * n.x + W[4] * n.y + W[8]  * n.z,
+                  W[1] * n.x + W[5] * n.y + W[9]  * n.z,
+                  W[2] * n.x + W[6] * n.y + W[10] * n.z);
+        h.GeometricNormal = normalize(g);
+    } else {                                               // HitInfo.hlsli:37-50
+        h.GeometricNormal = h.FlatNormal;
+    }
+    h.ShadingNormal = h.GeometricNormal;
+    h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
+    if (!h.IsFrontFace) h.ShadingNormal = -h.ShadingNormal;
+}
+
+PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
+
+// ---------------------------------------------------------------------------------------------
+// G-buffer (Shaders/GBufferGeneration.hlsl:116-232). One thread per local pixel, 16x16 tiles.
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, uint32_t flags, PtTextures tx,
+                                                 DeviceCounters* counters)
+{
+    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), ly = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= fv.width || ly >= fv.localRows) return;
+    const uint32_t y = global_row(fv, ly);
+    const size_t pi = (size_t)ly * fv.width + x;
+
+    float4 Position = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    float LinearDepth = INFINITY, NormalizedDepth = cam.IsNormalizedDepthReversed ? 0.0f : 1.0f;
+    float u, v;
+    const RayDesc ray = generate_pinhole_ray(cam, x, y, fv.width, fv.height, u, v);
+    int stack[kStackSize];
+    TraceStats st; st.nodes = 0; st.tris = 0;
+    const Hit hit = trace_closest<STATS>(sv.accel, ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
+    if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+
+    if (hit.inst != ~0u) {
+        SurfaceHit h;
+        reconstruct_hit(sv, hit.inst, hit.slot, hit.u, hit.v, ray.d, h);
+        if (flags & PT_GB_Geometry) {
+            Position = make_float4(h.Position.x, h.Position.y, h.Position.z, h.PositionOffset);
+            float ex, ey;
+            if ((flags & PT_GB_FlatNormal) && tx.FlatNormal) {
+                oct_encode(h.FlatNormal, ex, ey);
+                ((short2*)tx.FlatNormal)[pi] = make_short2(f32_to_snorm16(ex), f32_to_snorm16(ey));
+            }
+            if ((flags & PT_GB_GeometricNormal) && tx.GeometricNormal) {
+                oct_encode(h.GeometricNormal, ex, ey);
+                ((short2*)tx.GeometricNormal)[pi] = make_short2(f32_to_snorm16(ex), f32_to_snorm16(ey));
+            }
+            float proj[4]; xform4(cam.WorldToProjection, h.Position, proj);
+            LinearDepth = proj[3];
+            NormalizedDepth = proj[2] / proj[3];
+            if ((flags & PT_GB_MotionVector) && tx.MotionVector) {          // CalculateMotionVector :62-91 (no per-vertex motion buffers)
+                v3 prev = h.Position;
+                if (!sd.IsStatic && sv.instanceData) {
+                    const float* P = sv.instanceData[h.InstanceIndex].PreviousObjectToWorld; v3 q = h.ObjectPosition;
+                    prev = V3(P[0] * q.x + P[1] * q.y + P[2] * q.z + P[3], P[4] * q.x + P[5] * q.y + P[6] * q.z + P[7], P[8] * q.x + P[9] * q.y + P[10] * q.z + P[11]);
+                }
+                float clip[4], view[4];
+                xform4(cam.PreviousWorldToProjection, prev, clip);
+                xform4(cam.PreviousWorldToView, prev, view);
+                float su = (clip[0] / clip[3]) * 0.5f + 0.5f, svv = (clip[1] / clip[3]) * -0.5f + 0.5f;
+                ushort4 mv = make_ushort4(f32_to_f16((su - u) * (float)fv.width), f32_to_f16((svv - v) * (float)fv.height), f32_to_f16(view[2] - LinearDepth), 0);
+                ((ushort4*)tx.MotionVector)[pi] = mv;
+            }
+        }
+        BSDFSample bs; bs.Roughness = 0.0f;
+        if (flags & PT_GB_Material) {
+            const PtMaterial m = sv.objects[h.ObjectIndex].Material;      // EvaluateMaterial, untextured (ShadingHelpers.hlsli:161-235)
+            bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
+            if (tx.BaseColorMetalness)
+                ((uchar4*)tx.BaseColorMetalness)[pi] = make_uchar4(f32_to_unorm8(bs.BaseColor.x), f32_to_unorm8(bs.BaseColor.y), f32_to_unorm8(bs.BaseColor.z), f32_to_unorm8(bs.Metallic));
+            if (tx.IOR) ((uint16_t*)tx.IOR)[pi] = f32_to_f16(m.IOR);
+            if (bs.Metallic < 1.0f && tx.Transmission) ((uint8_t*)tx.Transmission)[pi] = f32_to_unorm8(bs.Transmission);
+            if ((flags & PT_GB_Radiance) && tx.Radiance) {
+                v3 e = material_emission(m);
+                ((ushort4*)tx.Radiance)[pi] = make_ushort4(f32_to_f16(e.x), f32_to_f16(e.y), f32_to_f16(e.z), 0);
+            }
+        }
+        if ((flags & PT_GB_NormalRoughness) && tx.NormalRoughness) {
+            float r = (flags & PT_GB_Material) ? bs.Roughness : 0.0f;
+            ((short4*)tx.NormalRoughness)[pi] = make_short4(f32_to_snorm16(h.ShadingNormal.x), f32_to_snorm16(h.ShadingNormal.y), f32_to_snorm16(h.ShadingNormal.z), f32_to_snorm16(r));
+        }
+    } else {
+        if ((flags & PT_GB_MotionVector) && tx.MotionVector) {
+            v3 far = ray.o + ray.d * 1e8f;                                  // CastRay miss position, RaytracingHelpers.hlsli:64
+            float proj[4], clip[4], view[4];
+            xform4(cam.WorldToProjection, far, proj);
+            xform4(cam.PreviousWorldToProjection, far, clip);
+            xform4(cam.PreviousWorldToView, far, view);
+            float su = (clip[0] / clip[3]) * 0.5f + 0.5f, svv = (clip[1] / clip[3]) * -0.5f + 0.5f;
+            ((ushort4*)tx.MotionVector)[pi] = make_ushort4(f32_to_f16((su - u) * (float)fv.width), f32_to_f16((svv - v) * (float)fv.height), f32_to_f16(view[2] - proj[3]), 0);
+        }
+        if ((flags & PT_GB_Radiance) && tx.Radiance) {
+            v3 e = environment_light_color(sd, ray.d);
+            ((ushort4*)tx.Radiance)[pi] = make_ushort4(f32_to_f16(e.x), f32_to_f16(e.y), f32_to_f16(e.z), 0);
+        }
+    }
+    if ((flags & PT_GB_Position) && tx.Position) ((float4*)tx.Position)[pi] = Position;
+    if ((flags & PT_GB_LinearDepth) && tx.LinearDepth) ((float*)tx.LinearDepth)[pi] = LinearDepth;
+    if ((flags & PT_GB_NormalizedDepth) && tx.NormalizedDepth) ((float*)tx.NormalizedDepth)[pi] = NormalizedDepth;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wavefront path tracer
+// ---------------------------------------------------------------------------------------------
+// enqueue every primary-hit pixel (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t* count)
+{
+    const uint32_t npix = fv.width * fv.localRows;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < npix; base += gridDim.x * blockDim.x) {
+        const uint32_t p = base + threadIdx.x;
+        bool alive = false;
+        if (p < npix) alive = isfinite(((const float4*)tx.Position)[p].w);
+        const unsigned long long m = __ballot(alive);
+        const uint32_t total = (uint32_t)__popcll(m);
+        uint32_t slot0 = 0;
+        if (lane == 0 && total) slot0 = atomicAdd(count, total);
+        slot0 = __shfl(slot0, 0);
+        if (alive) {
+            const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t x = p % fv.width, y = global_row(fv, p / fv.width);
+            q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
+            q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng_init(x, y, gs.FrameIndex)));
+            q.s2[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));            // sample 0, bounce 0, fresh
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, PtGraphicsSettings gs, PtTextures tx,
+                                               PathQueue qin, PathQueue qout, const uint32_t* countIn, uint32_t* countOut)
+{
+    const uint32_t n = *countIn;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        v3 thr = V3(1, 1, 1), srad = V3(0, 0, 0), rsum = V3(0, 0, 0), newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        uint32_t pixel = 0, rng = 0, sample = 0, bounce = 0;
+        if (i < n) {
+            const float4 a = qin.s0[i], b = qin.s1[i], c = qin.s2[i];
+            thr = V3(a.x, a.y, a.z); pixel = __float_as_uint(a.w);
+            srad = V3(b.x, b.y, b.z); rng = __float_as_uint(b.w);
+            rsum = V3(c.x, c.y, c.z);
+            const uint32_t cnt = __float_as_uint(c.w);
+            sample = cnt >> 16; bounce = (cnt >> 1) & 0x7FFFu;
+            bool pending = !(cnt & 1u);                                    // a traced ray's hit record is waiting
+            const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
+            float uu, vv;
+            const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // Raytracing.hlsl:110-126
+
+            while (true) {
+                SurfaceHit h; BSDFSample bs; v3 emission = V3(0, 0, 0), rayDir; bool isHit = true;
+                if (pending) {                                             // bounce >= 1, Raytracing.hlsl:219-233 done by k_extend
+                    pending = false;
+                    const uint4 hr = qin.hit[i];
+                    const float4 rd = qin.r1[i];
+                    rayDir = V3(rd.x, rd.y, rd.z);
+                    if (hr.x == ~0u) {                                     // :241-259
+                        srad = srad + thr * environment_light_color(sd, rayDir);
+                        isHit = false;
+                    } else {                                               // :293-304
+                        reconstruct_hit(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+                        const PtMaterial m = sv.objects[h.ObjectIndex].Material;
+                        emission = material_emission(m);
+                        bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
+                    }
+                } else {                                                   // bounce 0: primary surface from the G-buffer, :118-148
+                    bounce = 0;
+                    rayDir = primaryRay.d;
+                    const float4 pos = ((const float4*)tx.Position)[pixel];
+                    const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
+                    const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
+                    const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
+                    const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
+                    h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;      // HitInfo.hlsli:67-79
+                    h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
+                    h.GeometricNormal = oct_decode(snorm16_to_f32(ge.x), snorm16_to_f32(ge.y));
+                    h.ShadingNormal = V3(snorm16_to_f32(nr.x), snorm16_to_f32(nr.y), snorm16_to_f32(nr.z));
+                    h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
+                    emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));     // :119,197
+                    const float metal = unorm8_to_f32(bcm.w);
+                    const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
+                    const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
+                    bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
+                }
+                bool continues = false;
+                if (isHit) {
+                    srad = srad + thr * emission;                          // :320
+                    const SurfaceVectors svec = surface_vectors(h.IsFrontFace, h.GeometricNormal, h.ShadingNormal);
+                    const v3 V = -rayDir;
+                    float w[3]; bs.ComputeLobeWeights(svec, V, gs.ExtFlags, w);
+                    float rnd[4];
+                    rnd[0] = rng_float(rng); rnd[1] = rng_float(rng); rnd[2] = rng_float(rng); rnd[3] = rng_float(rng);   // GetFloat4, :330
+                    v3 L; int lobe;
+                    if (bs.Sample(svec, V, w, rnd, L, lobe)) {
+                        float pdf; v3 f;
+                        bs.EvaluateLobe(svec, L, V, w, lobe, gs.ExtFlags, pdf, f);
+                        if (pdf != 0.0f && !(f.x == 0.0f && f.y == 0.0f && f.z == 0.0f)) {       // :336,342
+                            thr = thr * V3(f.x / pdf, f.y / pdf, f.z / pdf);                     // :346
+                            bool survive = true;
+                            if (gs.IsRussianRouletteEnabled && bounce > 3) {                     // :348-356
+                                const float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
+                                if (rng_float(rng) >= p) survive = false;
+                                else thr = V3(thr.x / p, thr.y / p, thr.z / p);
+                            }
+                            if (survive && !(ml_luminance(thr) <= gs.ThroughputThreshold)        // :361
+                                && bounce < gs.Bounces) {                                        // loop bound, :213
+                                continues = true;
+                                newO = safe_world_ray_origin(h.Position, h.FlatNormal, h.PositionOffset, L);   // :221
+                                newD = L;
+                                bounce++;
+                            }
+                        }
+                    }
+                }
+                if (continues) { alive = true; break; }
+                rsum = rsum + srad;                                        // :372
+                sample++;
+                if (sample < gs.SamplesPerPixel) { thr = V3(1, 1, 1); srad = V3(0, 0, 0); continue; }
+                // pixel finished: :377-386
+                v3 out = V3(0, 0, 0);
+                if (finite3(rsum)) { const float ns = (float)gs.SamplesPerPixel; out = V3(rsum.x / ns, rsum.y / ns, rsum.z / ns); }
+                ((ushort4*)tx.Radiance)[pixel] = make_ushort4(f32_to_f16(out.x), f32_to_f16(out.y), f32_to_f16(out.z), 0);
+                if (tx.RadianceF32) ((float4*)tx.RadianceF32)[pixel] = make_float4(out.x, out.y, out.z, 0.0f);
+                break;
+            }
+        }
+        // wave64 compaction of the surviving paths into the output queue
+        const unsigned long long m = __ballot(alive);
+        const uint32_t total = (uint32_t)__popcll(m);
+        uint32_t slot0 = 0;
+        if (lane == 0 && total) slot0 = atomicAdd(countOut, total);
+        slot0 = __shfl(slot0, 0);
+        if (alive) {
+            const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            qout.s0[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
+            qout.s1[slot] = make_float4(srad.x, srad.y, srad.z, __uint_as_float(rng));
+            qout.s2[slot] = make_float4(rsum.x, rsum.y, rsum.z, __uint_as_float((sample << 16) | (bounce << 1)));
+            qout.r0[slot] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
+            qout.r1[slot] = make_float4(newD.x, newD.y, newD.z, INFINITY);                // TMax = inf, :224
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, const uint32_t* count, DeviceCounters* counters)
+{
+    const uint32_t n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
+    int stack[kStackSize];
+    TraceStats st; st.nodes = 0; st.tris = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 o = q.r0[i], d = q.r1[i];
+        const Hit h = trace_closest<STATS>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+    }
+    if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+}
+
+__global__ void k_count_primary(DeviceCounters* counters, unsigned long long n) { atomicAdd(&counters->primaryRays, n); }
+
+// dst[y][x] <- gathered per-rank band buffers (PtSharding layout)
+__global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, const uint64_t* rankOffsets, uint32_t rankCount, uint32_t bandHeight,
+                               uint32_t width, uint32_t height, uint32_t pixelBytes)
+{
+    const uint64_t rowBytes = (uint64_t)width * pixelBytes, chunks = rowBytes / 4;
+    const uint64_t total = chunks * height;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t y = (uint32_t)(t / chunks); const uint64_t cx = t % chunks;
+        const uint32_t band = y / bandHeight, rank = band % rankCount, localRow = (band / rankCount) * bandHeight + (y - band * bandHeight);
+        ((uint32_t*)(dst + (uint64_t)y * rowBytes))[cx] = ((const uint32_t*)(src + rankOffsets[rank] + (uint64_t)localRow * rowBytes))[cx];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static uint32_t persistent_grid(int device)
+{
+    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    return (uint32_t)p.multiProcessorCount * 8u;
+}
+
+hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx)
+{
+    if (fv.localRows == 0 || fv.width == 0) return hipSuccess;
+    dim3 grid((fv.width + 15) / 16, (fv.localRows + 15) / 16);
+    if (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) k_gbuffer<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+    else k_gbuffer<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+    k_count_primary<<<1, 1, 0, c.stream>>>(c.counters, (unsigned long long)fv.width * fv.localRows);
+    return hipGetLastError();
+}
+
+static hipError_t ensure_queues(Context& c, uint32_t capacity, uint32_t iterations)
+{
+    hipError_t e;
+    if (capacity > c.queueCapacity) {
+        for (int k = 0; k < 2; k++) {
+            PathQueue& q = c.queue[k];
+            void** ptrs[6] = { (void**)&q.s0, (void**)&q.s1, (void**)&q.s2, (void**)&q.r0, (void**)&q.r1, (void**)&q.hit };
+            for (auto pp : ptrs) { if (*pp) hipFree(*pp); *pp = nullptr; if ((e = hipMalloc(pp, (size_t)capacity * 16)) != hipSuccess) return e; }
+        }
+        c.queueCapacity = capacity;
+    }
+    if (iterations + 2 > c.queueCountsCap) {
+        if (c.queueCounts) hipFree(c.queueCounts);
+        c.queueCountsCap = iterations + 2;
+        if ((e = hipMalloc((void**)&c.queueCounts, sizeof(uint32_t) * c.queueCountsCap)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static void timing_begin(Context& c, std::vector<hipEvent_t>& ev, uint32_t k)
+{
+    if (!c.timing) return;
+    while (ev.size() < 2 * (size_t)(k + 1)) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
+    hipEventRecord(ev[2 * k], c.stream);
+}
+static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if (c.timing) hipEventRecord(ev[2 * k + 1], c.stream); }
+
+hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx)
+{
+    const PtGraphicsSettings& gs = c.settings;
+    const uint32_t npix = fv.width * fv.localRows;
+    c.nExtend = c.nShade = 0; c.lastIterations = 0;
+    if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
+    // every wavefront round traces at most one ray per path, a pixel traces at most spp*Bounces rays
+    const uint32_t rounds = gs.SamplesPerPixel * gs.Bounces;
+    hipError_t e = ensure_queues(c, npix, rounds + 1);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 3), c.stream)) != hipSuccess) return e;
+    const uint32_t grid = persistent_grid(c.device);
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], &c.queueCounts[0]);
+    const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
+    for (uint32_t r = 0; r <= rounds; r++) {
+        PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+        timing_begin(c, c.evShade, c.nShade);
+        k_shade<<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, &c.queueCounts[r], &c.queueCounts[r + 1]);
+        timing_end(c, c.evShade, c.nShade); c.nShade++;
+        if (r == rounds) break;
+        timing_begin(c, c.evExtend, c.nExtend);
+        if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
+        else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
+        timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
+    }
+    c.lastIterations = rounds + 1;
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsDev, uint32_t rankCount,
+                               uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes)
+{
+    k_deinterleave<<<2048, 256, 0, stream>>>((uint8_t*)dst, (const uint8_t*)src, rankOffsetsDev, rankCount, bandHeight, width, height, pixelBytes);
+    return hipGetLastError();
+}
+
+} // namespace pt

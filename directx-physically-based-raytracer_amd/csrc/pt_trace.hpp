@@ -1,0 +1,217 @@
+// pt_trace.hpp -- two-level BVH traversal + watertight ray/triangle test (device code, gfx950).
+//
+// Replaces the DXR hardware traversal behind RayQuery::TraceRayInline/Proceed that the reference
+// calls from TraceRay (Shaders/RaytracingHelpers.hlsli:7-55) with ray flags NONE, instance mask
+// ~0, RAY_FLAG_SKIP_PROCEDURAL_PRIMITIVES: closest hit, no face culling. No RT hardware and no
+// HIP-RT: boxes and triangles are plain fp32 VALU work.
+//
+// Node format (64 B, two child boxes per node, children sorted at traversal time):
+//   f4[0] = c0.lo.x c0.hi.x c0.lo.y c0.hi.y     f4[1] = c1.lo.x c1.hi.x c1.lo.y c1.hi.y
+//   f4[2] = c0.lo.z c0.hi.z c1.lo.z c1.hi.z     i4[3] = child0 child1 - -
+//   child >= 0: node index; child < 0: leaf ~x. BLAS leaf x = first_tri << 3 | (count-1);
+//   TLAS leaf x = instance slot. An absent child has an inverted (+inf,-inf) box.
+// Triangle packet (48 B): v0.xyz geom | v1.xyz prim | v2.xyz flags  -- object-space positions in
+// Morton order so a leaf's triangles are contiguous.
+#pragma once
+#include "pt_math.hpp"
+
+namespace pt {
+
+struct alignas(16) BvhNode { float4 c0xy, c1xy, cz; int4 child; };
+struct alignas(16) TriPacket { float4 a, b, c; };        // a.w = geom (bits), b.w = prim (bits), c.w = flags
+static_assert(sizeof(BvhNode) == 64 && sizeof(TriPacket) == 48, "layout");
+
+struct alignas(16) InstanceRecord {                       // 128 B, traversal + shading view of one TLAS instance
+    float worldToObject[12];
+    float objectToWorld[12];
+    const BvhNode* nodes;                                 // BLAS node pool (root = 0)
+    const TriPacket* tris;
+    uint32_t instanceID;                                  // D3D12 InstanceID = FirstGeometryIndex
+    uint32_t mask;
+    uint32_t _pad[2];
+};
+static_assert(sizeof(InstanceRecord) == 128, "layout");
+
+struct AccelView {
+    const BvhNode* tlasNodes;
+    const InstanceRecord* instances;
+    uint32_t instanceCount;
+};
+
+struct Hit {
+    float t, u, v;
+    uint32_t inst, geom, prim;                            // inst == ~0u : miss
+    uint32_t slot;                                        // index of the triangle packet inside its BLAS
+};
+
+struct TraceStats { uint32_t nodes, tris; };
+
+constexpr int kEntryDone = 0x7FFFFFFF;
+constexpr int kEntryRestore = 0x7FFFFFFE;
+constexpr int kStackSize = 96;
+
+struct RaySetup { int kx, ky, kz; float Sx, Sy, Sz; };
+
+// Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection", JCGT 2013 -- per-ray part.
+PT_DEV RaySetup ray_setup(v3 d)
+{
+    RaySetup r;
+    int kz = 0; float m = fabsf(d.x);
+    if (fabsf(d.y) > m) { kz = 1; m = fabsf(d.y); }
+    if (fabsf(d.z) > m) { kz = 2; }
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dz = comp(d, kz);
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = comp(d, kx) / dz;
+    r.Sy = comp(d, ky) / dz;
+    r.Sz = 1.0f / dz;
+    return r;
+}
+
+// Per-triangle part; fp64 recomputation of the edge functions when one is exactly 0 (paper's
+// fallback) keeps shared edges watertight. Returns t,u,v (u weights v1, v weights v2: DXR barycentrics).
+PT_DEV bool tri_test(const RaySetup& r, v3 o, v3 v0, v3 v1, v3 v2, float& t, float& u, float& v)
+{
+    v3 A = v0 - o, B = v1 - o, C = v2 - o;
+    float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
+    float Ax = comp(A, r.kx) - r.Sx * Akz, Ay = comp(A, r.ky) - r.Sy * Akz;
+    float Bx = comp(B, r.kx) - r.Sx * Bkz, By = comp(B, r.ky) - r.Sy * Bkz;
+    float Cx = comp(C, r.kx) - r.Sx * Ckz, Cy = comp(C, r.ky) - r.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    float det = U + V + W;
+    if (det == 0.0f) return false;
+    float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+    float T = U * Az + V * Bz + W * Cz;
+    float rcp = 1.0f / det;
+    t = T * rcp; u = V * rcp; v = W * rcp;
+    return true;
+}
+
+// Closest hit with ties on t broken by (instance, geometry, primitive) so the result does not
+// depend on traversal order. Triangle hits are accepted for t in (tmin, tmax) exclusive.
+PT_DEV void commit(Hit& h, float tmin, float t, float u, float v, uint32_t inst, uint32_t geom, uint32_t prim, uint32_t slot)
+{
+    if (!(t > tmin)) return;
+    bool better;
+    if (t < h.t) better = true;
+    else if (t == h.t && h.inst != ~0u)
+        better = inst < h.inst || (inst == h.inst && (geom < h.geom || (geom == h.geom && prim < h.prim)));
+    else better = false;
+    if (better) { h.t = t; h.u = u; h.v = v; h.inst = inst; h.geom = geom; h.prim = prim; h.slot = slot; }
+}
+
+// slab test against the two child boxes of a node; conservative: NaN slabs are ignored
+// (v_min/v_max drop NaN operands) and tfar is widened by 2 ulp.
+PT_DEV void node_test(const BvhNode& n, v3 idir, v3 ood, float tmin, float tmax,
+                      bool& hit0, bool& hit1, float& tn0, float& tn1)
+{
+    float c0lox = __builtin_fmaf(n.c0xy.x, idir.x, -ood.x), c0hix = __builtin_fmaf(n.c0xy.y, idir.x, -ood.x);
+    float c0loy = __builtin_fmaf(n.c0xy.z, idir.y, -ood.y), c0hiy = __builtin_fmaf(n.c0xy.w, idir.y, -ood.y);
+    float c0loz = __builtin_fmaf(n.cz.x, idir.z, -ood.z),   c0hiz = __builtin_fmaf(n.cz.y, idir.z, -ood.z);
+    float c1lox = __builtin_fmaf(n.c1xy.x, idir.x, -ood.x), c1hix = __builtin_fmaf(n.c1xy.y, idir.x, -ood.x);
+    float c1loy = __builtin_fmaf(n.c1xy.z, idir.y, -ood.y), c1hiy = __builtin_fmaf(n.c1xy.w, idir.y, -ood.y);
+    float c1loz = __builtin_fmaf(n.cz.z, idir.z, -ood.z),   c1hiz = __builtin_fmaf(n.cz.w, idir.z, -ood.z);
+    tn0 = fmaxf(fmaxf(fminf(c0lox, c0hix), fminf(c0loy, c0hiy)), fmaxf(fminf(c0loz, c0hiz), tmin));
+    float tf0 = fminf(fminf(fmaxf(c0lox, c0hix), fmaxf(c0loy, c0hiy)), fminf(fmaxf(c0loz, c0hiz), tmax));
+    tn1 = fmaxf(fmaxf(fminf(c1lox, c1hix), fminf(c1loy, c1hiy)), fmaxf(fminf(c1loz, c1hiz), tmin));
+    float tf1 = fminf(fminf(fmaxf(c1lox, c1hix), fmaxf(c1loy, c1hiy)), fminf(fmaxf(c1loz, c1hiz), tmax));
+    hit0 = tn0 <= tf0 * 1.0000004f;
+    hit1 = tn1 <= tf1 * 1.0000004f;
+}
+
+PT_DEV v3 safe_inv(v3 d)
+{
+    // 1/0 = inf is fine for the slab test (NaN slabs are ignored); keep IEEE division.
+    return V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
+// TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
+template <bool STATS>
+PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax, int* stack, TraceStats* stats)
+{
+    Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
+    if (av.instanceCount == 0) return h;
+
+    v3 ro = o, rd = d;                               // current-space ray (world, then object)
+    v3 idir = safe_inv(rd), ood = ro * idir;
+    RaySetup rs; rs.kx = rs.ky = rs.kz = 0; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    const BvhNode* nodes = av.tlasNodes;
+    const TriPacket* tris = nullptr;
+    uint32_t curInst = ~0u;
+    bool bottom = false;
+
+    int sp = 0;
+    stack[sp++] = kEntryDone;
+    int cur = 0;
+    while (true) {
+        // ---- descend through internal nodes
+        while (cur >= 0 && cur < kEntryRestore) {
+            const BvhNode n = nodes[cur];
+            if (STATS) stats->nodes++;
+            bool h0, h1; float t0, t1;
+            node_test(n, idir, ood, tmin, h.t, h0, h1, t0, t1);
+            if (h0 && h1) {
+                int nearc = n.child.x, farc = n.child.y;
+                if (t1 < t0) { nearc = n.child.y; farc = n.child.x; }
+                if (sp < kStackSize) stack[sp++] = farc;
+                cur = nearc;
+            } else if (h0) cur = n.child.x;
+            else if (h1) cur = n.child.y;
+            else cur = stack[--sp];
+        }
+        if (cur == kEntryDone) break;
+        if (cur == kEntryRestore) {                  // leave the BLAS: back to the world-space ray
+            ro = o; rd = d; idir = safe_inv(rd); ood = ro * idir;
+            nodes = av.tlasNodes; bottom = false;
+            cur = stack[--sp];
+            continue;
+        }
+        // ---- leaf
+        const uint32_t x = (uint32_t)~cur;
+        if (!bottom) {
+            const InstanceRecord* ir = &av.instances[x];
+            if (ir->mask & 0xFFu) {
+                const float* W = ir->worldToObject;
+                ro = V3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3],
+                        W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7],
+                        W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
+                rd = V3(W[0] * d.x + W[1] * d.y + W[2]  * d.z,
+                        W[4] * d.x + W[5] * d.y + W[6]  * d.z,
+                        W[8] * d.x + W[9] * d.y + W[10] * d.z);
+                idir = safe_inv(rd); ood = ro * idir;
+                rs = ray_setup(rd);
+                nodes = ir->nodes; tris = ir->tris; curInst = x; bottom = true;
+                if (sp < kStackSize) stack[sp++] = kEntryRestore;
+                cur = 0;
+                continue;
+            }
+        } else {
+            const uint32_t first = x >> 3, count = (x & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const TriPacket tp = tris[first + i];
+                if (STATS) stats->tris++;
+                float t, u, v;
+                if (tri_test(rs, ro, V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), t, u, v))
+                    commit(h, tmin, t, u, v, curInst, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), first + i);
+            }
+        }
+        cur = stack[--sp];
+    }
+    if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
+    return h;
+}
+
+} // namespace pt

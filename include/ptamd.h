@@ -1,0 +1,272 @@
+/*
+ * ptamd.h -- C ABI of the MI355X-native wavefront path tracer (libptamd.so).
+ *
+ * Drop-in boundary for ONE hot path of Hydr10n/DirectX-Physically-Based-Raytracer:
+ *     GBufferGeneration::Render  (Source/GBufferGeneration.ixx:80-117 -> Shaders/GBufferGeneration.hlsl:116-232)
+ *     Raytracing::Render         (Source/Raytracing.ixx:106-112      -> Shaders/Raytracing.hlsl:103-415, DEFAULT)
+ *     acceleration-structure build (Source/Scene.ixx:286-380, Source/RaytracingHelpers.ixx:28-105,
+ *                                   Source/CommandList.ixx:217-249)
+ * Every entry point cites the reference interface it replaces. Plain pointers and sizes only:
+ * no C++ types, no torch types. All `const void*` "device" arguments are HIP device pointers
+ * owned by the caller; structs passed by pointer are HOST memory copied during the call.
+ * Work is enqueued on the context's HIP stream (pt_set_stream) and is asynchronous unless
+ * stated otherwise; pt_sync() blocks until it has completed.
+ *
+ * Error convention: every function returns PT_OK (0) or a negative PtStatus; the message is
+ * available from pt_last_error(). Nothing throws across this boundary. (The reference throws
+ * std::system_error / std::invalid_argument: Source/ErrorHelpers.ixx:16-32,
+ * Source/RaytracingHelpers.ixx:83-88 -- the C++ mirror in directx-physically-based-raytracer_amd/host/
+ * turns the status back into those exceptions.)
+ */
+#ifndef PTAMD_H
+#define PTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTAMD_ABI_VERSION 1
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERROR_INVALID_ARGUMENT = -1,   /* reference: Throw<std::invalid_argument> */
+    PT_ERROR_HIP = -2,                /* reference: ThrowIfFailed(HRESULT) */
+    PT_ERROR_OUT_OF_MEMORY = -3,
+    PT_ERROR_NOT_READY = -4,          /* render before an acceleration structure exists */
+    PT_ERROR_NO_DEVICE = -5
+} PtStatus;
+
+/* ------------------------------------------------------------------------------------------
+ * Reference data layouts, byte-exact. Field names are the reference's.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PtVertexDesc {             /* Source/Vertex.ixx:30-36, Shaders/Vertex.hlsli:5-12 */
+    uint32_t Stride, _pad[3];
+    struct { uint32_t Normal, Tangent, TextureCoordinates[2]; } AttributeOffsets;   /* ~0u = absent */
+} PtVertexDesc;
+
+typedef struct PtMeshDescriptors {        /* Source/CommonShaderData.ixx:28-30; indices into the descriptor heap */
+    uint32_t Vertices, Indices, MotionVectors, _pad;
+} PtMeshDescriptors;
+
+typedef struct PtMaterial {               /* Source/Material.ixx:12-20, Shaders/Material.hlsli:8-22 */
+    float BaseColor[4];
+    float EmissiveStrength;
+    float EmissiveColor[3];
+    float Metallic, Roughness, IOR, Transmission;
+    uint32_t AlphaMode;                   /* 0 Opaque, 1 Mask, 2 Blend */
+    float AlphaCutoff;
+    uint32_t _pad[2];
+} PtMaterial;
+
+typedef struct PtTextureMapInfo {         /* Source/Material.ixx:35-38 */
+    uint32_t Descriptor, TextureCoordinateIndex, _pad[2];
+} PtTextureMapInfo;
+
+typedef struct PtObjectData {             /* Source/CommonShaderData.ixx:34-39 */
+    PtVertexDesc VertexDesc;
+    PtMeshDescriptors MeshDescriptors;
+    PtMaterial Material;
+    PtTextureMapInfo TextureMapInfoArray[7];
+} PtObjectData;
+
+typedef struct PtInstanceData {           /* Source/CommonShaderData.ixx:22-26 */
+    uint32_t FirstGeometryIndex, _pad[3];
+    float PreviousObjectToWorld[12];      /* XMFLOAT3X4: rows of the column-vector affine [R|t] */
+    float ObjectToWorld[12];
+} PtInstanceData;
+
+typedef struct PtSceneData {              /* Source/CommonShaderData.ixx:15-20 */
+    uint32_t IsStatic, IsEnvironmentLightTextureCubeMap;
+    uint32_t EnvironmentLightTextureDescriptor, _pad;
+    float EnvironmentLightColor[4];       /* a < 0 selects the procedural sky (Shaders/ShadingHelpers.hlsli:25-29) */
+    float EnvironmentLightTransform[12];
+} PtSceneData;
+
+typedef struct PtCamera {                 /* Source/Camera.ixx:16-36, Shaders/Camera.hlsli:5-25 */
+    uint32_t IsNormalizedDepthReversed;
+    float PreviousPosition[3], Position[3], _pad0;
+    float RightDirection[3], _pad1;
+    float UpDirection[3], _pad2;
+    float ForwardDirection[3];
+    float ApertureRadius, NearDepth, FarDepth;
+    float Jitter[2];
+    float PreviousWorldToView[16], PreviousViewToProjection[16], PreviousWorldToProjection[16],
+          PreviousProjectionToView[16], PreviousViewToWorld[16], WorldToProjection[16],
+          ProjectionToView[16], ViewToWorld[16];
+} PtCamera;
+
+typedef struct PtGraphicsSettings {       /* Raytracing::GraphicsSettings, Source/Raytracing.ixx:30-36,151-166 */
+    uint32_t RenderSize[2];
+    uint32_t FrameIndex, Bounces, SamplesPerPixel;
+    float ThroughputThreshold;            /* reference default 1e-3 */
+    uint32_t IsRussianRouletteEnabled, IsShaderExecutionReorderingEnabled, IsDIEnabled;
+    uint32_t Denoiser;                    /* only 0 (None) is implemented */
+    uint32_t ExtFlags;                    /* reference: first padding word. PT_EXT_* build-side switches */
+    uint32_t _pad;
+    uint32_t SHARC[8];                    /* out of scope, ignored */
+} PtGraphicsSettings;
+
+#define PT_EXT_LAMBERTIAN_ONLY 0x1u       /* BASELINE.json config C1: lobe weights {1,0,0}, DiffuseTerm = 1/pi */
+
+typedef struct PtGBufferConstants {       /* GBufferGeneration::Constants, Source/GBufferGeneration.ixx:46-49 */
+    uint32_t RenderSize[2];
+    uint32_t Flags;                       /* PtGBufferFlags */
+} PtGBufferConstants;
+
+enum PtGBufferFlags {                     /* Source/GBufferGeneration.ixx:28-44 */
+    PT_GB_Position = 0x1, PT_GB_FlatNormal = 0x2, PT_GB_GeometricNormal = 0x4, PT_GB_LinearDepth = 0x8,
+    PT_GB_NormalizedDepth = 0x10, PT_GB_MotionVector = 0x20, PT_GB_DiffuseAlbedo = 0x40,
+    PT_GB_SpecularAlbedo = 0x80, PT_GB_Albedo = 0xC0, PT_GB_NormalRoughness = 0x100, PT_GB_Radiance = 0x200,
+    PT_GB_Geometry = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x100,
+    PT_GB_Material = 0x400 | 0xC0 | 0x100 | 0x200
+};
+
+/* The G-buffer "textures": linear row-major device arrays, one element per pixel of the LOCAL
+ * framebuffer (see PtSharding), in the reference's DXGI formats (Source/App.cpp:438-455).
+ * Same member order as GBufferGeneration::Textures (Source/GBufferGeneration.ixx:53-68);
+ * Raytracing::Textures (Source/Raytracing.ixx:46-59) is the subset the path tracer reads plus
+ * Radiance. NULL = not bound. DiffuseAlbedo / SpecularAlbedo are denoiser-only and never written. */
+typedef struct PtTextures {
+    void* Position;            /* R32G32B32A32_FLOAT  16 B : xyz world position, w = spawn offset; all +inf on miss */
+    void* FlatNormal;          /* R16G16_SNORM         4 B : signed octahedral */
+    void* GeometricNormal;     /* R16G16_SNORM         4 B */
+    void* LinearDepth;         /* R32_FLOAT            4 B */
+    void* NormalizedDepth;     /* R32_FLOAT            4 B */
+    void* MotionVector;        /* R16G16B16A16_FLOAT   8 B */
+    void* BaseColorMetalness;  /* R8G8B8A8_UNORM       4 B */
+    void* DiffuseAlbedo;       /* unused */
+    void* SpecularAlbedo;      /* unused */
+    void* NormalRoughness;     /* R16G16B16A16_SNORM   8 B */
+    void* IOR;                 /* R16_FLOAT            2 B */
+    void* Transmission;        /* R8_UNORM             1 B */
+    void* Radiance;            /* R16G16B16A16_FLOAT   8 B : G-buffer emission/environment in, path-traced radiance out */
+    void* RadianceF32;         /* build-side extra, optional: R32G32B32A32_FLOAT copy of the value stored to Radiance */
+} PtTextures;
+
+/* ------------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PtContext PtContext;
+
+int  pt_abi_version(void);
+/* One context per GPU (reference: one D3D12 device, Source/DeviceResources.cpp:101-170). */
+int  pt_create(int device_ordinal, PtContext** out_ctx);
+void pt_destroy(PtContext* ctx);
+const char* pt_last_error(const PtContext* ctx);            /* ctx may be NULL: last error of pt_create */
+/* hipStream_t to enqueue on (NULL = the default stream). Reference: CommandList recording order. */
+int  pt_set_stream(PtContext* ctx, void* hip_stream);
+int  pt_sync(PtContext* ctx);                               /* reference: CommandList::End/Wait, Source/CommandList.ixx:86-119 */
+
+/* ------------------------------------------------------------------------------------------
+ * descriptor heap analogue. ObjectData.MeshDescriptors.{Vertices,Indices} index this table
+ * (reference: ResourceDescriptorHeap[...], Shaders/RaytracingHelpers.hlsli:82-85).
+ * stride: element size of a typed buffer (index buffer: 2 = R16_UINT or 4 = R32_UINT), 0 for raw buffers.
+ * ------------------------------------------------------------------------------------------ */
+int  pt_heap_resize(PtContext* ctx, uint32_t descriptor_count);
+int  pt_heap_set_buffer(PtContext* ctx, uint32_t descriptor, const void* device_ptr, uint64_t bytes, uint32_t stride);
+
+/* ------------------------------------------------------------------------------------------
+ * acceleration structures
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PtGeometryDesc {           /* D3D12_RAYTRACING_GEOMETRY_DESC as filled by CreateGeometryDesc,
+                                             Source/RaytracingHelpers.ixx:76-105 */
+    const void* VertexBuffer;             /* device; position = 3 x f32 at offset 0 of each vertex */
+    uint32_t VertexCount, VertexStride;
+    const void* IndexBuffer;              /* device */
+    uint32_t IndexCount, IndexStride;     /* stride 2 or 4; count divisible by 3 (else PT_ERROR_INVALID_ARGUMENT) */
+    uint32_t Flags;                       /* PT_GEOMETRY_FLAG_OPAQUE */
+    uint32_t _pad;
+} PtGeometryDesc;
+#define PT_GEOMETRY_FLAG_OPAQUE 0x1u      /* Source/Scene.ixx:320-324 */
+
+#define PT_BUILD_FLAG_ALLOW_UPDATE      0x01u
+#define PT_BUILD_FLAG_PREFER_FAST_TRACE 0x04u
+#define PT_BUILD_FLAG_PREFER_FAST_BUILD 0x08u
+
+/* Bottom level: one per MeshNode, one geometry per Mesh (Source/Scene.ixx:286-341 ->
+ * CommandList::BuildAccelerationStructures, Source/CommandList.ixx:217-233). Returns an id
+ * (reference: RTXMU accel-struct id). The LBVH is built on the device, on the context stream. */
+int  pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint32_t geometry_count,
+                           uint32_t build_flags, uint64_t* out_blas_id);
+int  pt_release_bottom_level(PtContext* ctx, uint64_t blas_id);       /* Scene::CollectGarbage, Source/Scene.ixx:382-387 */
+
+typedef struct PtInstanceDesc {           /* D3D12_RAYTRACING_INSTANCE_DESC as filled at Source/Scene.ixx:365-377 */
+    float Transform[12];
+    uint32_t InstanceID;                  /* = InstanceData.FirstGeometryIndex; ObjectIndex = InstanceID + GeometryIndex */
+    uint32_t InstanceMask;                /* low 8 bits; 0 hides the instance */
+    uint64_t AccelerationStructure;       /* blas id */
+} PtInstanceDesc;
+
+/* Top level over all mesh-node instances (BuildTopLevelAccelerationStructure,
+ * Source/RaytracingHelpers.ixx:28-74). descs is HOST memory. Rebuilds if one already exists. */
+int  pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t count, uint32_t build_flags);
+
+typedef struct PtAccelStats {
+    uint32_t InstanceCount, BottomLevelCount;
+    uint64_t TriangleCount;               /* sum over instances */
+    uint64_t NodeBytes, TriangleBytes;    /* device memory held by BVH nodes / triangle packets */
+    uint32_t NodeSizeBytes, TriangleSizeBytes;
+} PtAccelStats;
+int  pt_get_accel_stats(PtContext* ctx, PtAccelStats* out);           /* synchronises */
+
+/* ------------------------------------------------------------------------------------------
+ * per-frame inputs (reference: the GPUBuffers slots the caller fills before each Render,
+ * Source/GBufferGeneration.ixx:51, Source/Raytracing.ixx:44; filled at Source/App.cpp:540-561,1016-1074)
+ * ------------------------------------------------------------------------------------------ */
+int  pt_set_camera(PtContext* ctx, const PtCamera* camera);                          /* host struct, copied */
+int  pt_set_scene_data(PtContext* ctx, const PtSceneData* scene_data);               /* host struct, copied */
+int  pt_set_object_data(PtContext* ctx, const PtObjectData* device_objects, uint32_t count);     /* device array, referenced */
+int  pt_set_instance_data(PtContext* ctx, const PtInstanceData* device_instances, uint32_t count); /* device array, referenced */
+
+/* Multi-GPU framebuffer sharding (not a reference feature). The frame is cut into
+ * horizontal bands of BandHeight rows; band b belongs to rank b % RankCount. A context renders
+ * only its own bands; its textures hold those rows contiguously (local row = (b / RankCount) *
+ * BandHeight + row-in-band). RNG seeds and camera rays use GLOBAL pixel coordinates, so the
+ * gathered image is bit-identical to a single-GPU one. RankCount = 1 disables sharding. */
+typedef struct PtSharding { uint32_t RankIndex, RankCount, BandHeight, _pad; } PtSharding;
+int  pt_set_sharding(PtContext* ctx, const PtSharding* sharding);
+int  pt_local_rows(const PtSharding* sharding, uint32_t frame_height, uint32_t* out_rows);
+/* dst_full[H][W] (pixel_bytes each) <- gathered[rank][local rows][W] (what a gather of every rank's
+ * local buffer yields, rank r at byte offset rank_offsets[r]). Device pointers; enqueued on the stream. */
+int  pt_deinterleave_bands(PtContext* ctx, void* dst_full, const void* gathered, const uint64_t* rank_offsets_host,
+                           uint32_t rank_count, uint32_t band_height, uint32_t width, uint32_t height, uint32_t pixel_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * the two operators
+ * ------------------------------------------------------------------------------------------ */
+/* GBufferGeneration::Render(commandList, topLevelAccelerationStructure, constants),
+ * Source/GBufferGeneration.ixx:80-117. Primary pinhole ray per pixel, closest hit, G-buffer stores. */
+int  pt_gbuffer_render(PtContext* ctx, const PtGBufferConstants* constants, const PtTextures* textures);
+
+/* Raytracing::SetConstants + Raytracing::Render (Source/Raytracing.ixx:92-112): spp x (Bounces+1)
+ * path-tracing loop per pixel, wavefront-scheduled; reads the G-buffer textures written by
+ * pt_gbuffer_render for bounce 0 and stores the per-pixel radiance. */
+int  pt_raytrace_set_constants(PtContext* ctx, const PtGraphicsSettings* settings);
+int  pt_raytrace_render(PtContext* ctx, const PtTextures* textures);
+
+/* Measurement (no reference counterpart). Counters cover the work enqueued since the last reset;
+ * reading them synchronises the stream. */
+typedef struct PtCounters {
+    uint64_t PrimaryRays;         /* rays cast by pt_gbuffer_render */
+    uint64_t SecondaryRays;       /* rays cast by pt_raytrace_render (bounce rays actually traced) */
+    uint64_t NodesVisited;        /* BVH node fetches   (only with PT_DEBUG_TRAVERSAL_STATS) */
+    uint64_t TrianglesTested;     /* triangle tests     (only with PT_DEBUG_TRAVERSAL_STATS) */
+    uint64_t WavefrontIterations; /* extend/shade rounds launched by the last pt_raytrace_render */
+    uint64_t _reserved[3];
+} PtCounters;
+int  pt_reset_counters(PtContext* ctx);
+int  pt_get_counters(PtContext* ctx, PtCounters* out);
+#define PT_DEBUG_TRAVERSAL_STATS 0x1u
+int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
+
+/* Timing of the traversal ("extend") kernel, measured with HIP events on the context stream around
+ * every extend launch of the last pt_raytrace_render when enabled. Synchronises. */
+int  pt_enable_kernel_timing(PtContext* ctx, int enable);
+int  pt_get_kernel_timing(PtContext* ctx, float* extend_ms, float* shade_ms, uint32_t* extend_launches, uint32_t* shade_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTAMD_H */
