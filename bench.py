@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: Mrays/s (whole job) + frames/s, Cornell Box 1080p 4 spp / 8 bounces.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one frame of the hot path on synthetic inputs already resident in HBM:
+GBufferGeneration::Render + Raytracing::Render (Source/App.cpp:1196-1328) and, for N > 1, the RCCL gather
+of the per-rank row bands to rank 0 + de-interleave. The frame is sharded by 16-row bands (band b -> rank b % N),
+total work is fixed as N grows => "scaling": "strong". Rays = primary (G-buffer) + secondary rays actually
+traced, counted on the device. One JSON line is printed by rank 0.
+
+Extra objects in the line (DESIGN.md "Measurement"):
+  roofline      dominant kernel of the frame: algorithmic bytes / HIP-event time of its launches vs 8 TB/s HBM
+  cpu_baseline  the CPU oracle (oracle/, OpenMP) timed on this host on a bounded row slab of the same frame
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+BAND = 16
+
+WORKLOADS = {
+    # name: (scene factory kwargs, width, height, spp, bounces, description)
+    "c2": ("cornell", 1920, 1080, 4, 8, "Cornell Box 1920x1080 4spp 8 bounces full GGX metallic-roughness (BASELINE configs[1])"),
+    "c3": ("sponza", 1920, 1080, 1, 8, "Sponza-scale ~250k tris 1920x1080 1spp 8 bounces + RR (BASELINE configs[2])"),
+    "c4": ("cornell", 3840, 2160, 16, 16, "Cornell Box 3840x2160 16spp 16 bounces (BASELINE configs[3])"),
+    "c5": ("grid", 1920, 1080, 4, 8, "10k instances two-level BVH 1920x1080 4spp 8 bounces (BASELINE configs[4])"),
+    "c1": ("cornell_lambert", 256, 256, 1, 2, "Cornell Box 256x256 1spp 2 bounces Lambertian only (BASELINE configs[0])"),
+}
+
+
+def make_scene(kind, aspect, S):
+    if kind == "cornell":
+        return S.cornell_box(aspect=aspect, variant="ggx"), 0
+    if kind == "cornell_lambert":
+        return S.cornell_box(aspect=aspect, variant="diffuse"), 1
+    if kind == "sponza":
+        return S.sponza_scale(aspect=aspect), 0
+    if kind == "grid":
+        return S.instanced_grid(n=100, aspect=aspect), 0
+    raise ValueError(kind)
+
+
+def cpu_baseline(scene, gs, W, H, L, budget_s=15.0):
+    """Time the oracle (kind "port": the C restatement, OpenMP over scanlines, its own BVH) on a row slab."""
+    oracle = ge.load_oracle()
+    osc = oracle.OracleScene(scene, accel_mode=1)
+    gb = {k: np.zeros((H, W, c), dt) for k, (dt, c) in L.GBUFFER_FORMATS.items()}
+    consts = np.zeros((), L.GBUFFER_CONSTANTS)
+    consts["RenderSize"] = (W, H); consts["Flags"] = L.GBufferFlags.DefaultNoDenoiser
+    cores = os.cpu_count() or 1
+
+    def slab(rows):
+        y0 = max(0, H // 2 - rows // 2); y1 = min(H, y0 + rows)
+        t = time.perf_counter()
+        rays = osc.gbuffer(consts, gb, rows=(y0, y1))
+        rays += osc.raytrace(gs, gb, rows=(y0, y1))
+        return rays, time.perf_counter() - t, (y0, y1)
+
+    rays, dt, _ = slab(8)                                   # calibration (also warms the threads up)
+    rows = int(min(H, max(8, 8 * budget_s / max(dt, 1e-4))))
+    rays, dt, (y0, y1) = slab(rows)
+    reps = 1
+    while dt < 0.66 * budget_s and reps < 64:               # fast hosts: repeat the slab until ~budget_s of CPU work
+        r2, d2, _ = slab(rows)
+        rays += r2; dt += d2; reps += 1
+    osc.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows {y0}..{y1} of the {W}x{H} frame x{reps} ({rays} rays in {dt:.2f} s), oracle/pt_oracle.c with its own BVH, OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    ge.load_package()
+    import dxpbrt_amd.layouts as L
+    import dxpbrt_amd.ptamd as P
+    import dxpbrt_amd.scenes as S
+    import dxpbrt_amd.sharding as SH
+
+    kind, W, H, spp, bounces, desc = WORKLOADS[args.workload]
+    scene, ext = make_scene(kind, W / H, S)
+    stream = torch.cuda.current_stream(device)
+    ctx = P.DeviceContext(local_rank, stream=stream.cuda_stream)
+    ctx.set_sharding(rank, world, BAND)
+    gpu_scene = P.Scene(ctx, scene, device)
+    renderer = P.Renderer(ctx, gpu_scene, W, H)
+    max_rows = max(P.local_rows(H, r, world, BAND) for r in range(world))
+    if world > 1:                                           # equal-sized gather pieces
+        renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
+        for op in (renderer.gbuffer, renderer.raytracing):
+            op.Textures = renderer.textures
+    full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if rank == 0 else None
+    gathered_flat = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and world > 1) else None
+    offsets = (np.arange(world, dtype=np.uint64) * np.uint64(max_rows * W * 8))
+
+    def step(frame_index):
+        gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame_index, ext_flags=ext)
+        renderer.render(gs)
+        if world > 1:
+            SH.gather_to_root(renderer.textures["Radiance"], rank, world, dist, out=gathered_flat)
+            if rank == 0:
+                ctx.check(ctx.lib.pt_deinterleave_bands(ctx.handle, full.data_ptr(), gathered_flat.data_ptr(), offsets.ctypes.data,
+                                                        world, BAND, W, H, 8))
+        return gs
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ctx.reset_counters()
+    timing = world == 1
+    if timing:
+        ctx.enable_kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        gs = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    c = ctx.counters()
+    kt = ctx.kernel_timing() if timing else None
+    ctx.enable_kernel_timing(False)
+
+    rays_local = float(c.PrimaryRays + c.SecondaryRays)
+    t = torch.tensor([elapsed, rays_local, float(c.SecondaryRays)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_total, secondary_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        rays_total, secondary_total = rays_local, float(c.SecondaryRays)
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "Mrays/s per GPU + frames/s at 1080p, Cornell Box 4spp/8bounce",
+            "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "frames_per_s": args.steps / elapsed, "mrays_per_s_per_gpu": rays_total / elapsed / 1e6 / world,
+            "rays_per_frame": rays_total / args.steps,
+            "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces,
+                       "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
+                       "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py)"},
+        }
+
+    # ---- roofline of the dominant kernel (N = 1): one extra frame with traversal statistics for B_bvh
+    if rank == 0 and timing:
+        ctx.set_debug_flags(1)
+        ctx.reset_counters()
+        step(args.warmup + args.steps - 1)
+        cs = ctx.counters()
+        ctx.set_debug_flags(0)
+        rays_frame = max(1, cs.SecondaryRays)
+        node_b, tri_b = 64, 48
+        bvh_bytes_per_ray = (cs.NodesVisited * node_b + cs.TrianglesTested * tri_b) / float(cs.PrimaryRays + cs.SecondaryRays)
+        ext_ms, sh_ms = kt["extend_ms"], kt["shade_ms"]
+        sec_rays = secondary_total
+        # algorithmic bytes per secondary ray (DESIGN.md / SURVEY 8d): extend = ray read 32 + hit write 16 + B_bvh;
+        # shade = ray write 32 + hit read 16 + path state 48 r + 48 w + hit geometry 108
+        kernels = {
+            "k_extend": {"ms": ext_ms, "launches": kt["extend_launches"], "bytes": sec_rays * (48.0 + bvh_bytes_per_ray)},
+            "k_shade": {"ms": sh_ms, "launches": kt["shade_launches"], "bytes": sec_rays * 252.0},
+        }
+        dom = max(kernels, key=lambda k: kernels[k]["ms"])
+        kd = kernels[dom]
+        achieved = kd["bytes"] / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
+            "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
+            "bvh_bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / float(cs.PrimaryRays + cs.SecondaryRays),
+            "tris_per_ray": cs.TrianglesTested / float(cs.PrimaryRays + cs.SecondaryRays),
+            "other_kernel": {k: {"ms_total": v["ms"], "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
+                             for k, v in kernels.items() if k != dom},
+            "note": "event time summed over the timed steps; bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
+        }
+        del rays_frame
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

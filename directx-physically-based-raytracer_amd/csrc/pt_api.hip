@@ -196,7 +196,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         r.nodes = it->second.nodes; r.tris = it->second.tris;
         r.instanceID = descs[i].InstanceID & 0xFFFFFFu;
         r.mask = descs[i].InstanceMask & 0xFFu;
-        r._pad[0] = r._pad[1] = 0;
+        r.triCount = it->second.triCount; r._pad = 0;
         bounds[i] = it->second.rootBounds;
         tris += it->second.triCount;
     }
@@ -377,6 +377,19 @@ int pt_get_counters(PtContext* ctx, PtCounters* out)
     out->PrimaryRays = d.primaryRays; out->SecondaryRays = d.secondaryRays;
     out->NodesVisited = d.nodesVisited; out->TrianglesTested = d.trianglesTested;
     out->WavefrontIterations = c.lastIterations;
+    out->BvhMismatches = d.mismatchCount;
+    return PT_OK;
+}
+
+int pt_debug_read_mismatch(PtContext* ctx, float* out16)
+{
+    if (!ctx || !out16) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_HIP(&c, hipSetDevice(c.device));
+    DeviceCounters d;
+    API_HIP(&c, hipMemcpyAsync(&d, c.counters, sizeof d, hipMemcpyDeviceToHost, c.stream));
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    memcpy(out16, d.mismatchRay, sizeof(float) * 16);
     return PT_OK;
 }
 
@@ -391,6 +404,7 @@ int pt_enable_kernel_timing(PtContext* ctx, int enable)
 {
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     ctx->c.timing = enable != 0;
+    ctx->c.nExtend = ctx->c.nShade = 0;          // accumulation restarts
     return PT_OK;
 }
 

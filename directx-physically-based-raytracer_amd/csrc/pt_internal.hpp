@@ -56,6 +56,8 @@ struct PathQueue {
 
 struct DeviceCounters {
     unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
+    unsigned int mismatchCount, _pad;        // PT_DEBUG_BRUTE_FORCE: rays whose LBVH result differs from brute force
+    float mismatchRay[16];                   // first such ray: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t -
 };
 
 struct Context {

@@ -342,6 +342,28 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCam
     }
 }
 
+__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q, const uint32_t* count, DeviceCounters* counters)
+{
+    const uint32_t n = *count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
+    int stack[kStackSize];
+    TraceStats st; st.nodes = 0; st.tris = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 o = q.r0[i], d = q.r1[i];
+        const Hit h = trace_brute_force(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w);
+        const Hit b = trace_closest<false>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        if (b.inst != h.inst || (h.inst != ~0u && (b.slot != h.slot || b.u != h.u || b.v != h.v))) {
+            if (atomicAdd(&counters->mismatchCount, 1u) == 0u) {
+                float* m = counters->mismatchRay;
+                m[0] = o.x; m[1] = o.y; m[2] = o.z; m[3] = o.w; m[4] = d.x; m[5] = d.y; m[6] = d.z; m[7] = d.w;
+                m[8] = __uint_as_float(b.inst); m[9] = __uint_as_float(b.slot); m[10] = b.t; m[11] = 0.0f;
+                m[12] = __uint_as_float(h.inst); m[13] = __uint_as_float(h.slot); m[14] = h.t; m[15] = 0.0f;
+            }
+        }
+        q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+    }
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, const uint32_t* count, DeviceCounters* counters)
 {
@@ -422,7 +444,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 {
     const PtGraphicsSettings& gs = c.settings;
     const uint32_t npix = fv.width * fv.localRows;
-    c.nExtend = c.nShade = 0; c.lastIterations = 0;
+    c.lastIterations = 0;
     if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
     // every wavefront round traces at most one ray per path, a pixel traces at most spp*Bounces rays
     const uint32_t rounds = gs.SamplesPerPixel * gs.Bounces;
@@ -439,7 +461,8 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
-        if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
+        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
+        else if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
         else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }

@@ -28,7 +28,8 @@ struct alignas(16) InstanceRecord {                       // 128 B, traversal + 
     const TriPacket* tris;
     uint32_t instanceID;                                  // D3D12 InstanceID = FirstGeometryIndex
     uint32_t mask;
-    uint32_t _pad[2];
+    uint32_t triCount;                                    // triangles in the BLAS (debug brute-force traversal)
+    uint32_t _pad;
 };
 static_assert(sizeof(InstanceRecord) == 128, "layout");
 
@@ -132,11 +133,15 @@ PT_DEV void node_test(const BvhNode& n, v3 idir, v3 ood, float tmin, float tmax,
     hit1 = tn1 <= tf1 * 1.0000004f;
 }
 
-PT_DEV v3 safe_inv(v3 d)
+PT_DEV float safe_inv1(float d)
 {
-    // 1/0 = inf is fine for the slab test (NaN slabs are ignored); keep IEEE division.
-    return V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // A zero (or denormal-small) direction component would turn the slab planes into inf - inf = NaN,
+    // and max(-inf, NaN) = -inf then culls a box the ray is inside of. Clamp |d| for the BOX test only
+    // (the triangle test uses the true direction): planes become +-huge finite values with the right signs.
+    const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+    return 1.0f / a;
 }
+PT_DEV v3 safe_inv(v3 d) { return V3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
 
 // TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
 template <bool STATS>
@@ -209,6 +214,32 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
             }
         }
         cur = stack[--sp];
+    }
+    if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
+    return h;
+}
+
+// Debug / validation traversal (PT_DEBUG_BRUTE_FORCE): every triangle of every instance, no BVH.
+PT_DEV Hit trace_brute_force(const AccelView& av, v3 o, v3 d, float tmin, float tmax)
+{
+    Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
+    for (uint32_t x = 0; x < av.instanceCount; x++) {
+        const InstanceRecord* ir = &av.instances[x];
+        if (!(ir->mask & 0xFFu)) continue;
+        const float* W = ir->worldToObject;
+        v3 ro = V3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3],
+                   W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7],
+                   W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
+        v3 rd = V3(W[0] * d.x + W[1] * d.y + W[2]  * d.z,
+                   W[4] * d.x + W[5] * d.y + W[6]  * d.z,
+                   W[8] * d.x + W[9] * d.y + W[10] * d.z);
+        const RaySetup rs = ray_setup(rd);
+        for (uint32_t i = 0; i < ir->triCount; i++) {
+            const TriPacket tp = ir->tris[i];
+            float t, u, v;
+            if (tri_test(rs, ro, V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), t, u, v))
+                commit(h, tmin, t, u, v, x, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), i);
+        }
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;

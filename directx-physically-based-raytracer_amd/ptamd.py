@@ -24,7 +24,7 @@ EXPORTS = [
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_reset_counters", "pt_get_counters",
-    "pt_set_debug_flags", "pt_enable_kernel_timing", "pt_get_kernel_timing",
+    "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_enable_kernel_timing", "pt_get_kernel_timing",
 ]
 
 
@@ -60,7 +60,8 @@ class Sharding(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("PrimaryRays", C.c_uint64), ("SecondaryRays", C.c_uint64), ("NodesVisited", C.c_uint64),
-                ("TrianglesTested", C.c_uint64), ("WavefrontIterations", C.c_uint64), ("_reserved", C.c_uint64 * 3)]
+                ("TrianglesTested", C.c_uint64), ("WavefrontIterations", C.c_uint64), ("BvhMismatches", C.c_uint64),
+                ("_reserved", C.c_uint64 * 2)]
 
 
 class AccelStats(C.Structure):
@@ -103,6 +104,7 @@ def load_library():
         lib.pt_gbuffer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pt_reset_counters.argtypes = [C.c_void_p]
         lib.pt_set_debug_flags.argtypes = [C.c_void_p, C.c_uint32]
+        lib.pt_debug_read_mismatch.argtypes = [C.c_void_p, C.c_void_p]
         lib.pt_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.pt_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

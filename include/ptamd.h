@@ -254,15 +254,19 @@ typedef struct PtCounters {
     uint64_t NodesVisited;        /* BVH node fetches   (only with PT_DEBUG_TRAVERSAL_STATS) */
     uint64_t TrianglesTested;     /* triangle tests     (only with PT_DEBUG_TRAVERSAL_STATS) */
     uint64_t WavefrontIterations; /* extend/shade rounds launched by the last pt_raytrace_render */
-    uint64_t _reserved[3];
+    uint64_t BvhMismatches;       /* PT_DEBUG_BRUTE_FORCE: rays whose LBVH result differed from brute force (must be 0) */
+    uint64_t _reserved[2];
 } PtCounters;
 int  pt_reset_counters(PtContext* ctx);
 int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_TRAVERSAL_STATS 0x1u
+#define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
+/* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
+int  pt_debug_read_mismatch(PtContext* ctx, float* out16);
 
-/* Timing of the traversal ("extend") kernel, measured with HIP events on the context stream around
- * every extend launch of the last pt_raytrace_render when enabled. Synchronises. */
+/* Per-kernel timing with HIP events recorded on the context stream around every extend / shade launch
+ * issued after pt_enable_kernel_timing(ctx, 1); the getter synchronises and returns the sums since then. */
 int  pt_enable_kernel_timing(PtContext* ctx, int enable);
 int  pt_get_kernel_timing(PtContext* ctx, float* extend_ms, float* shade_ms, uint32_t* extend_launches, uint32_t* shade_launches);
 

@@ -709,6 +709,9 @@ static inline void commit_candidate(Committed* c, float tmin, float t, float u, 
     if (better) { c->t = t; c->u = u; c->v = v; c->inst = inst; c->geom = geom; c->prim = prim; c->hit = 1; }
 }
 
+/* box test only: clamp |d| away from 0 so that slab planes never become inf - inf = NaN */
+static inline float safe_inv1(float d) { float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; return 1.0f / a; }
+
 static inline int box_test(const float lo[3], const float hi[3], f3 o, f3 inv, float tmin, float tmax)
 {
     float t0x = (lo[0] - o.x) * inv.x, t1x = (hi[0] - o.x) * inv.x;
@@ -731,7 +734,7 @@ static void blas_intersect(const Blas* b, int accel, f3 o, f3 d, float tmin, uin
         return;
     }
     if (!b->n_nodes) return;
-    f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    f3 inv = F3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
     uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const Node* n = &b->nodes[stack[--sp]];
@@ -769,7 +772,7 @@ static Committed trace_ray(const OrScene* s, f3 o, f3 d, float tmin, float tmax)
     if (!s->accel_mode) {
         for (uint32_t i = 0; i < s->n_inst; i++) instance_intersect(s, i, o, d, tmin, &c);
     } else if (s->n_tl_nodes) {
-        f3 inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        f3 inv = F3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z));
         uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
         while (sp) {
             const Node* n = &s->tl_nodes[stack[--sp]];

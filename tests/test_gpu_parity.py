@@ -1,0 +1,268 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through size-independent
+properties (determinism, sharding invariance, ray-count bounds, monotonicity).
+
+Tolerance (BASELINE.json north_star): per-pixel L2 radiance error < 1e-3 vs the oracle. Scenes whose whole
+arithmetic is bit-pinned (Cornell box: no libm call on the path) are additionally required to be BIT-IDENTICAL;
+scenes with the procedural sky go through powf (Color::FromSrgb) and are held to the 1e-3 / 1e-5 tolerances.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+_spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)
+
+L2_TOLERANCE = 1e-3          # per-pixel L2 radiance (rms over the image), north_star
+SKY_ABS_TOLERANCE = 2e-5     # max per-pixel deviation allowed where powf (procedural sky) is involved
+
+
+def gpu_render(ptamd, ctx, scene, gs, W, H, sharding=(0, 1, 16), stats=False):
+    ctx.set_sharding(*sharding)
+    g = ptamd.Scene(ctx, scene)
+    r = ptamd.Renderer(ctx, g, W, H, with_f32=True)
+    ctx.set_debug_flags(1 if stats else 0)
+    ctx.reset_counters()
+    r.render(gs)
+    ctx.sync()
+    c = ctx.counters()
+    out = ptamd.textures_to_numpy(r.textures)
+    ctx.set_debug_flags(0)
+    ctx.set_sharding(0, 1, 16)
+    return out, c
+
+
+GB_KEYS = ("Position", "FlatNormal", "GeometricNormal", "LinearDepth", "NormalizedDepth", "MotionVector",
+           "BaseColorMetalness", "NormalRoughness", "IOR")
+
+
+def assert_gbuffer_identical(out, ref):
+    for k in GB_KEYS:
+        a, b = out[k], ref[k]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        assert np.array_equal(a, b), f"G-buffer texture {k} differs from the oracle"
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.CASES))
+def test_golden_fixtures_bit_exact(name, gpu, ptamd):
+    """HIP path vs the committed golden vectors (no oracle code runs in this test)."""
+    make, W, H, spp, bounces, ext = make_golden.CASES[name]
+    ge.load_package()
+    import dxpbrt_amd.scenes as S
+    scene = make()
+    gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=7, ext_flags=ext)
+    out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    assert c.PrimaryRays + c.SecondaryRays == int(g["rays"])
+    assert np.array_equal(out["Position"].view(np.uint32), g["position"].view(np.uint32))
+    assert np.array_equal(out["FlatNormal"], g["flat_normal"])
+    assert np.array_equal(out["NormalRoughness"], g["normal_roughness"])
+    assert np.array_equal(out["BaseColorMetalness"], g["base_color_metalness"])
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), g["radiance_f32"].view(np.uint32))
+    assert np.array_equal(out["Radiance"], g["radiance_f16"])
+
+
+CORNELL_CASES = [
+    # variant, glass, normals, W, H, spp, bounces, rr, ext, jitter, frame
+    ("ggx", True, True, 160, 90, 4, 8, True, 0, (0.0, 0.0), 0),
+    ("ggx", False, True, 96, 96, 16, 16, True, 0, (0.31, -0.17), 5),        # C4-shaped: 16 spp x 16 bounces
+    ("diffuse", False, False, 256, 256, 1, 2, True, 1, (0.0, 0.0), 0),      # C1: Lambertian-only switch, no vertex normals
+    ("ggx", True, True, 64, 48, 2, 100, False, 0, (0.0, 0.0), 1),           # max Bounces (MyAppData.h:183), RR off
+    ("diffuse", True, True, 33, 17, 3, 5, True, 0, (-0.5, 0.49), 2),        # ragged size (not a multiple of 16 / 64)
+]
+
+
+@pytest.mark.parametrize("case", CORNELL_CASES, ids=lambda c: f"{c[0]}_{c[3]}x{c[4]}_s{c[5]}_b{c[6]}")
+def test_cornell_bit_identical_to_oracle(case, gpu, ptamd, oracle, pkg):
+    variant, glass, normals, W, H, spp, bounces, rr, ext, jitter, frame = case
+    S, L = pkg.scenes, pkg.layouts
+    scene = S.cornell_box(aspect=W / H, variant=variant, glass_sphere=glass, has_normals=normals, jitter=jitter)
+    gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame, russian_roulette=rr, ext_flags=ext)
+    out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+    ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)   # brute force: no BVH at all
+    assert_gbuffer_identical(out, ref_gb)
+    assert c.PrimaryRays == W * H and c.PrimaryRays + c.SecondaryRays == ref_rays
+    st = ge.compare_radiance(out["RadianceF32"], ref_f32)
+    assert st["rms"] < L2_TOLERANCE
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32)), st
+    assert np.array_equal(out["Radiance"], ref_gb["Radiance"])             # the fp16 texture the reference consumer reads
+
+
+def test_bounces_zero_and_misses(gpu, ptamd, oracle, pkg):
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 128, 32
+    scene = S.cornell_box(aspect=W / H)
+    scene.camera = S.make_camera((0, 0, -4.0), hfov_deg=90.0, aspect=W / H)   # rays beside the box miss
+    for bounces in (0, 3):
+        gs = S.graphics_settings(W, H, spp=2, bounces=bounces)
+        out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+        ref_gb, ref_rays, _ = oracle.render(scene, gs, accel_mode=0, layouts=L)
+        assert_gbuffer_identical(out, ref_gb)
+        assert np.array_equal(out["Radiance"], ref_gb["Radiance"])
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        miss = ~np.isfinite(out["Position"][..., 3])
+        assert miss.any() and np.all(np.isinf(out["Position"][miss]))
+
+
+def test_sky_instanced_and_large_mesh_within_tolerance(gpu, ptamd, oracle, pkg):
+    """Two-level BVH with many instances (C5-shaped) and a multi-geometry BLAS (C3-shaped), procedural sky."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 192, 108
+    for scene in (S.instanced_grid(n=24, aspect=W / H), S.sponza_scale(n_side=64, aspect=W / H)):
+        gs = S.graphics_settings(W, H, spp=2, bounces=6)
+        out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=1, want_f32=True, layouts=L)
+        assert_gbuffer_identical(out, ref_gb)                   # hits, positions, normals: no libm involved
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays      # identical path structure
+        st = ge.compare_radiance(out["RadianceF32"], ref_f32)
+        assert st["rms"] < L2_TOLERANCE and st["max"] < SKY_ABS_TOLERANCE, st
+
+
+def test_lbvh_agrees_with_brute_force_on_incoherent_rays(gpu, ptamd, oracle, pkg):
+    """LBVH traversal (conservative boxes, tie-break) vs the oracle's brute-force loop over every triangle."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 96, 54
+    scene = S.sponza_scale(n_side=40, aspect=W / H)
+    scene.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))   # constant environment: bit-pinned arithmetic
+    gs = S.graphics_settings(W, H, spp=2, bounces=8)
+    out, c = gpu_render(ptamd, gpu, scene, gs, W, H, stats=True)
+    ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+    assert_gbuffer_identical(out, ref_gb)
+    assert c.PrimaryRays + c.SecondaryRays == ref_rays
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+    assert c.NodesVisited > 0 and c.TrianglesTested > 0
+    # the hierarchy actually culls: far fewer triangle tests than brute force
+    assert c.TrianglesTested < 0.05 * (c.PrimaryRays + c.SecondaryRays) * scene.triangle_count
+
+
+def test_lbvh_vs_device_brute_force_no_mismatch(gpu, ptamd, pkg):
+    """PT_DEBUG_BRUTE_FORCE runs both traversals for every bounce ray on the device and counts disagreements.
+    Regression: a reflected ray with an exactly-zero direction component (axis-aligned walls produce them) used to
+    be culled by a NaN slab in the box test."""
+    S = pkg.scenes
+    cases = [(S.cornell_box(aspect=1.0, variant="ggx", jitter=(0.31, -0.17)), 96, 96, 16, 16, 5),
+             (S.instanced_grid(n=16, aspect=1.5), 96, 64, 2, 6, 0),
+             (S.sponza_scale(n_side=48, aspect=1.5), 96, 64, 2, 6, 0)]
+    for scene, W, H, spp, bounces, frame in cases:
+        gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame)
+        gpu.set_sharding(0, 1, 16)
+        g = ptamd.Scene(gpu, scene)
+        r = ptamd.Renderer(gpu, g, W, H)
+        gpu.set_debug_flags(2)
+        gpu.reset_counters()
+        r.render(gs)
+        gpu.sync()
+        c = gpu.counters()
+        gpu.set_debug_flags(0)
+        assert c.SecondaryRays > W * H and c.BvhMismatches == 0
+
+
+def test_deterministic_and_sharding_invariant(gpu, ptamd, pkg):
+    """Run twice: bit-identical. Render as rank r of 3 and of 8: the assembled frame equals the unsharded one
+    (RNG seeds and camera rays use global pixel coordinates)."""
+    S = pkg.scenes
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    W, H = 160, 90
+    scene = S.cornell_box(aspect=W / H, glass_sphere=True)
+    gs = S.graphics_settings(W, H, spp=3, bounces=6, frame_index=9)
+    a, ca = gpu_render(ptamd, gpu, scene, gs, W, H)
+    b, cb = gpu_render(ptamd, gpu, scene, gs, W, H)
+    assert np.array_equal(a["Radiance"], b["Radiance"]) and ca.SecondaryRays == cb.SecondaryRays
+    for world, band in ((3, 16), (8, 4)):
+        pieces, rays = [], 0
+        for r in range(world):
+            o, c = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(r, world, band))
+            assert o["Radiance"].shape[0] == SH.local_rows(H, r, world, band)
+            pieces.append(o["Radiance"]); rays += c.PrimaryRays + c.SecondaryRays
+        assert np.array_equal(SH.deinterleave(pieces, H, band), a["Radiance"])
+        assert rays == ca.PrimaryRays + ca.SecondaryRays
+
+
+def test_device_deinterleave(gpu, ptamd):
+    import ctypes as C
+    import torch
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    H, W, world, band = 45, 24, 4, 8
+    rng = np.random.default_rng(0)
+    full = rng.integers(0, 65535, (H, W, 4)).astype(np.uint16)
+    max_rows = max(SH.local_rows(H, r, world, band) for r in range(world))
+    gathered = np.zeros((world, max_rows, W, 4), np.uint16)
+    for r in range(world):
+        p = SH.extract_local(full, r, world, band)
+        gathered[r, :p.shape[0]] = p
+    d_g = torch.from_numpy(gathered.view(np.int16)).cuda()
+    d_out = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    offs = np.arange(world, dtype=np.uint64) * np.uint64(max_rows * W * 8)
+    gpu.check(gpu.lib.pt_deinterleave_bands(gpu.handle, d_out.data_ptr(), d_g.data_ptr(), offs.ctypes.data, world, band, W, H, 8))
+    gpu.sync()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint16), full)
+
+
+def test_full_size_properties_c2(gpu, ptamd, pkg):
+    """BASELINE configs[1] at full size (1920x1080, 4 spp, 8 bounces): properties that need no oracle."""
+    S = pkg.scenes
+    W, H = 1920, 1080
+    scene = S.cornell_box(aspect=W / H, variant="ggx")
+    gs = S.graphics_settings(W, H, spp=4, bounces=8)
+    a, ca = gpu_render(ptamd, gpu, scene, gs, W, H)
+    rays = ca.PrimaryRays + ca.SecondaryRays
+    assert ca.PrimaryRays == W * H and W * H < rays <= W * H * (1 + 4 * 8)
+    rad = a["RadianceF32"][..., :3]
+    assert np.isfinite(rad).all() and (rad >= 0).all() and 0.05 < rad.mean() < 5.0
+    assert np.all(np.isfinite(a["Position"][..., 3]))           # camera inside the opening: every primary ray hits
+    # fp16 output texture == rounding of the fp32 value
+    assert np.array_equal(a["Radiance"][..., :3], rad.astype(np.float16).view(np.uint16))
+    # idempotence: same inputs -> same bits
+    b, cb = gpu_render(ptamd, gpu, scene, gs, W, H)
+    assert np.array_equal(a["Radiance"], b["Radiance"]) and cb.SecondaryRays == ca.SecondaryRays
+    # linearity of the estimator in the emitter: doubling EmissiveStrength doubles every pixel exactly (power of two)
+    scene2 = S.cornell_box(aspect=W / H, variant="ggx")
+    scene2.nodes[5].meshes[0].material["EmissiveStrength"] = 30.0
+    scene2.finalize()
+    c2, _ = gpu_render(ptamd, gpu, scene2, gs, W, H)
+    assert np.array_equal(c2["RadianceF32"][..., :3], 2.0 * rad)
+    # a 2-rank sharded render of the same frame assembles to the same image
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    pieces = [gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(r, 2, 16))[0]["Radiance"] for r in range(2)]
+    assert np.array_equal(SH.deinterleave(pieces, H, 16), a["Radiance"])
+
+
+def test_error_behaviour(ptamd, pkg):
+    """status codes in place of the reference's exceptions (Source/RaytracingHelpers.ixx:83-88, ErrorHelpers.ixx)."""
+    import ctypes as C
+    import torch
+    S, L = pkg.scenes, pkg.layouts
+    ctx = ptamd.DeviceContext(0)
+    try:
+        k = np.zeros((), L.GBUFFER_CONSTANTS); k["RenderSize"] = (8, 8)
+        t = ptamd.Textures()
+        with pytest.raises(ptamd.PtError, match="top-level"):       # render before any acceleration structure
+            ctx.check(ctx.lib.pt_gbuffer_render(ctx.handle, C.c_void_p(k.ctypes.data), C.addressof(t)))
+        buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+        g = ptamd.GeometryDesc(buf.data_ptr(), 2, 32, buf.data_ptr(), 3, 3, 1, 0)
+        bid = C.c_uint64()
+        with pytest.raises(ptamd.PtInvalidArgument, match="uint16 or uint32"):
+            ctx.check(ctx.lib.pt_build_bottom_level(ctx.handle, C.addressof(g), 1, 0, C.byref(bid)))
+        g.IndexStride, g.IndexCount = 2, 4
+        with pytest.raises(ptamd.PtInvalidArgument, match="divisible by 3"):
+            ctx.check(ctx.lib.pt_build_bottom_level(ctx.handle, C.addressof(g), 1, 0, C.byref(bid)))
+        d = ptamd.InstanceDesc(); d.AccelerationStructure = 12345
+        with pytest.raises(ptamd.PtInvalidArgument, match="unknown bottom-level"):
+            ctx.check(ctx.lib.pt_build_top_level(ctx.handle, C.addressof(d), 1, 0))
+        # empty scene: builds, renders, every pixel is a miss with the environment colour
+        ctx.check(ctx.lib.pt_build_top_level(ctx.handle, None, 0, 0))
+        assert ctx.accel_stats().InstanceCount == 0
+    finally:
+        ctx.close()
