@@ -202,22 +202,45 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
 // ---------------------------------------------------------------------------------------------
 // wavefront path tracer
 // ---------------------------------------------------------------------------------------------
-// enqueue every primary-hit pixel (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
-__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t* count)
+// Queue geometry. The path queue is cut into kSubQueues independent sub-queues (segments of segCap entries,
+// each with its own counter): a single returning atomic on one word saturates near 88 M/s on MI355X, which
+// at one atomic per wave made compaction the bottleneck of the whole frame. Pixel tile t (256 pixels) is
+// dealt to sub-queue t % kSubQueues, a path never leaves its sub-queue, so a segment can never overflow and
+// every sub-queue samples the whole image (balanced). One atomic per 256-thread block and tile.
+constexpr uint32_t kSubQueues = 32;
+
+// block-wide stream compaction: wave64 ballot + prefix popcount inside each wave, wave totals through LDS,
+// ONE atomicAdd per block. Every thread of the block must call it. lds: 8 words.
+PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
 {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(alive);
+    const uint32_t prefix = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) lds[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[4] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = lds[4];
+    for (uint32_t w = 0; w < wave; w++) base += lds[w];
+    __syncthreads();
+    return base + prefix;
+}
+
+// enqueue every primary-hit pixel (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* counts)
+{
+    __shared__ uint32_t lds[8];
     const uint32_t npix = fv.width * fv.localRows;
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < npix; base += gridDim.x * blockDim.x) {
-        const uint32_t p = base + threadIdx.x;
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    for (uint32_t j = bq; (j * kSubQueues + sq) * 256u < npix; j += nbq) {
+        const uint32_t p = (j * kSubQueues + sq) * 256u + threadIdx.x;
         bool alive = false;
-        if (p < npix) alive = isfinite(((const float4*)tx.Position)[p].w);
-        const unsigned long long m = __ballot(alive);
-        const uint32_t total = (uint32_t)__popcll(m);
-        uint32_t slot0 = 0;
-        if (lane == 0 && total) slot0 = atomicAdd(count, total);
-        slot0 = __shfl(slot0, 0);
+        if (p < npix) alive = isfinite(((const float*)tx.Position)[4 * (size_t)p + 3]);
+        const uint32_t slot = sq * segCap + block_reserve(alive, &counts[sq], lds);
         if (alive) {
-            const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             const uint32_t x = p % fv.width, y = global_row(fv, p / fv.width);
             q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
             q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng_init(x, y, gs.FrameIndex)));
@@ -227,16 +250,18 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSetting
 }
 
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, PtGraphicsSettings gs, PtTextures tx,
-                                               PathQueue qin, PathQueue qout, const uint32_t* countIn, uint32_t* countOut)
+                                               PathQueue qin, PathQueue qout, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
-    const uint32_t n = *countIn;
-    const uint32_t lane = threadIdx.x & 63;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
+    __shared__ uint32_t lds[8];
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t n = countIn[sq];
+    for (uint32_t tile = bq; tile * 256u < n; tile += nbq) {
+        const uint32_t local = tile * 256u + threadIdx.x;
+        const uint32_t i = sq * segCap + local;
         bool alive = false;
         v3 thr = V3(1, 1, 1), srad = V3(0, 0, 0), rsum = V3(0, 0, 0), newO = V3(0, 0, 0), newD = V3(0, 0, 1);
         uint32_t pixel = 0, rng = 0, sample = 0, bounce = 0;
-        if (i < n) {
+        if (local < n) {
             const float4 a = qin.s0[i], b = qin.s1[i], c = qin.s2[i];
             thr = V3(a.x, a.y, a.z); pixel = __float_as_uint(a.w);
             srad = V3(b.x, b.y, b.z); rng = __float_as_uint(b.w);
@@ -325,14 +350,9 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCam
                 break;
             }
         }
-        // wave64 compaction of the surviving paths into the output queue
-        const unsigned long long m = __ballot(alive);
-        const uint32_t total = (uint32_t)__popcll(m);
-        uint32_t slot0 = 0;
-        if (lane == 0 && total) slot0 = atomicAdd(countOut, total);
-        slot0 = __shfl(slot0, 0);
+        // compaction of the surviving paths into the same sub-queue of the output queue
+        const uint32_t slot = sq * segCap + block_reserve(alive, &countOut[sq], lds);
         if (alive) {
-            const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             qout.s0[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
             qout.s1[slot] = make_float4(srad.x, srad.y, srad.z, __uint_as_float(rng));
             qout.s2[slot] = make_float4(rsum.x, rsum.y, rsum.z, __uint_as_float((sample << 16) | (bounce << 1)));
@@ -342,13 +362,15 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCam
     }
 }
 
-__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
-    const uint32_t n = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t n = count[sq];
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     int stack[kStackSize];
     TraceStats st; st.nodes = 0; st.tris = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
+        const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
         const Hit h = trace_brute_force(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w);
         const Hit b = trace_closest<false>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
@@ -365,13 +387,15 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q,
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
-    const uint32_t n = *count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t n = count[sq];
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     int stack[kStackSize];
     TraceStats st; st.nodes = 0; st.tris = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
+        const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
         const Hit h = trace_closest<STATS>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
@@ -400,7 +424,8 @@ __global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, const uint64_t*
 static uint32_t persistent_grid(int device)
 {
     hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
-    return (uint32_t)p.multiProcessorCount * 8u;
+    const uint32_t g = (uint32_t)p.multiProcessorCount * 8u;
+    return (g + kSubQueues - 1) / kSubQueues * kSubQueues;          // whole number of blocks per sub-queue
 }
 
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx)
@@ -424,9 +449,9 @@ static hipError_t ensure_queues(Context& c, uint32_t capacity, uint32_t iteratio
         }
         c.queueCapacity = capacity;
     }
-    if (iterations + 2 > c.queueCountsCap) {
+    if (iterations > c.queueCountsCap) {
         if (c.queueCounts) hipFree(c.queueCounts);
-        c.queueCountsCap = iterations + 2;
+        c.queueCountsCap = iterations;
         if ((e = hipMalloc((void**)&c.queueCounts, sizeof(uint32_t) * c.queueCountsCap)) != hipSuccess) return e;
     }
     return hipSuccess;
@@ -448,22 +473,25 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
     // every wavefront round traces at most one ray per path, a pixel traces at most spp*Bounces rays
     const uint32_t rounds = gs.SamplesPerPixel * gs.Bounces;
-    hipError_t e = ensure_queues(c, npix, rounds + 1);
+    const uint32_t tiles = (npix + 255u) / 256u;
+    const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
+    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * kSubQueues);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 3), c.stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * kSubQueues, c.stream)) != hipSuccess) return e;
     const uint32_t grid = persistent_grid(c.device);
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], &c.queueCounts[0]);
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], segCap, &c.queueCounts[0]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         timing_begin(c, c.evShade, c.nShade);
-        k_shade<<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, &c.queueCounts[r], &c.queueCounts[r + 1]);
+        uint32_t* cin = &c.queueCounts[r * kSubQueues]; uint32_t* cout = &c.queueCounts[(r + 1) * kSubQueues];
+        k_shade<<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
-        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
-        else if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
-        else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, &c.queueCounts[r + 1], c.counters);
+        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+        else if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+        else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }
     c.lastIterations = rounds + 1;
