@@ -214,6 +214,8 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "state_only": {"achieved": (sec_rays * (48.0 if dom == "k_extend" else 252.0)) / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0,
+                           "note": "queue/state bytes only, without B_bvh (BVH bytes of a cache-resident scene never reach HBM)"},
             "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
             "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
             "bvh_bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / float(cs.PrimaryRays + cs.SecondaryRays),

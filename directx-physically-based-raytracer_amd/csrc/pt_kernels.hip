@@ -16,6 +16,8 @@ namespace pt {
 // ---------------------------------------------------------------------------------------------
 // shared device helpers
 // ---------------------------------------------------------------------------------------------
+constexpr int kLdsStackDepth = 24;      // traversal stack entries per lane kept in LDS (24 KB per 256-thread block)
+
 struct RayDesc { v3 o, d; float tmin, tmax; };
 
 // Camera::GeneratePinholeRay (Shaders/Camera.hlsli:27-41), Math::CalculateUV/NDC (Shaders/Math.hlsli:7-15)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
                                                  DeviceCounters* counters)
 {
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), ly = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= fv.width || ly >= fv.localRows) return;
+    if (x >= fv.width || ly >= fv.localRows) return;          // no barrier below: early exit is safe
     const uint32_t y = global_row(fv, ly);
     const size_t pi = (size_t)ly * fv.width + x;
 
@@ -126,7 +128,9 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
     float LinearDepth = INFINITY, NormalizedDepth = cam.IsNormalizedDepthReversed ? 0.0f : 1.0f;
     float u, v;
     const RayDesc ray = generate_pinhole_ray(cam, x, y, fv.width, fv.height, u, v);
-    int stack[kStackSize];
+    __shared__ int ldsStack[kLdsStackDepth * 256];
+    int spill[kStackSize - kLdsStackDepth];
+    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
     TraceStats st; st.nodes = 0; st.tris = 0;
     const Hit hit = trace_closest<STATS>(sv.accel, ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
@@ -367,7 +371,9 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q,
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
-    int stack[kStackSize];
+    __shared__ int ldsStack[kLdsStackDepth * 256];
+    int spill[kStackSize - kLdsStackDepth];
+    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
     TraceStats st; st.nodes = 0; st.tris = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
@@ -392,7 +398,9 @@ __global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, uint3
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
-    int stack[kStackSize];
+    __shared__ int ldsStack[kLdsStackDepth * 256];
+    int spill[kStackSize - kLdsStackDepth];
+    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
     TraceStats st; st.nodes = 0; st.tris = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;

@@ -53,6 +53,26 @@ constexpr int kStackSize = 96;
 
 struct RaySetup { int kx, ky, kz; float Sx, Sy, Sz; };
 
+// Traversal stack: the first LDS_DEPTH entries of every lane live in LDS (entry d of thread t at
+// lds[d * blockDim + t]: consecutive lanes hit consecutive banks), deeper entries spill to a private array.
+template <int LDS_DEPTH>
+struct TraversalStack {
+    int* lds; int* spill; int sp;
+    PT_DEV void init(int* ldsBase, int* spillBase) { lds = ldsBase + threadIdx.x; spill = spillBase; sp = 0; }
+    PT_DEV void push(int v)
+    {
+        if (sp < LDS_DEPTH) lds[sp * 256] = v;
+        else if (sp < kStackSize) spill[sp - LDS_DEPTH] = v;
+        else return;
+        sp++;
+    }
+    PT_DEV int pop()
+    {
+        sp--;
+        return sp < LDS_DEPTH ? lds[sp * 256] : spill[sp - LDS_DEPTH];
+    }
+};
+
 // Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection", JCGT 2013 -- per-ray part.
 PT_DEV RaySetup ray_setup(v3 d)
 {
@@ -65,9 +85,9 @@ PT_DEV RaySetup ray_setup(v3 d)
     float dz = comp(d, kz);
     if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = comp(d, kx) / dz;
-    r.Sy = comp(d, ky) / dz;
-    r.Sz = 1.0f / dz;
+    r.Sz = 1.0f / dz;                    // one IEEE division; Sx, Sy by multiplication (spec, same in the oracle)
+    r.Sx = comp(d, kx) * r.Sz;
+    r.Sy = comp(d, ky) * r.Sz;
     return r;
 }
 
@@ -139,13 +159,13 @@ PT_DEV float safe_inv1(float d)
     // and max(-inf, NaN) = -inf then culls a box the ray is inside of. Clamp |d| for the BOX test only
     // (the triangle test uses the true direction): planes become +-huge finite values with the right signs.
     const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);      // 1 ulp v_rcp_f32: the box test is conservative (padded boxes), not part of the spec
 }
 PT_DEV v3 safe_inv(v3 d) { return V3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
 
 // TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
-template <bool STATS>
-PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax, int* stack, TraceStats* stats)
+template <bool STATS, typename STACK>
+PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax, STACK& stack, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     if (av.instanceCount == 0) return h;
@@ -158,8 +178,8 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
     uint32_t curInst = ~0u;
     bool bottom = false;
 
-    int sp = 0;
-    stack[sp++] = kEntryDone;
+    stack.sp = 0;
+    stack.push(kEntryDone);
     int cur = 0;
     while (true) {
         // ---- descend through internal nodes
@@ -171,17 +191,17 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
             if (h0 && h1) {
                 int nearc = n.child.x, farc = n.child.y;
                 if (t1 < t0) { nearc = n.child.y; farc = n.child.x; }
-                if (sp < kStackSize) stack[sp++] = farc;
+                stack.push(farc);
                 cur = nearc;
             } else if (h0) cur = n.child.x;
             else if (h1) cur = n.child.y;
-            else cur = stack[--sp];
+            else cur = stack.pop();
         }
         if (cur == kEntryDone) break;
         if (cur == kEntryRestore) {                  // leave the BLAS: back to the world-space ray
             ro = o; rd = d; idir = safe_inv(rd); ood = ro * idir;
             nodes = av.tlasNodes; bottom = false;
-            cur = stack[--sp];
+            cur = stack.pop();
             continue;
         }
         // ---- leaf
@@ -199,7 +219,7 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
                 idir = safe_inv(rd); ood = ro * idir;
                 rs = ray_setup(rd);
                 nodes = ir->nodes; tris = ir->tris; curInst = x; bottom = true;
-                if (sp < kStackSize) stack[sp++] = kEntryRestore;
+                stack.push(kEntryRestore);
                 cur = 0;
                 continue;
             }
@@ -213,7 +233,7 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
                     commit(h, tmin, t, u, v, curInst, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), first + i);
             }
         }
-        cur = stack[--sp];
+        cur = stack.pop();
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;

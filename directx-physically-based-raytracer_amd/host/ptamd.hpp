@@ -7,7 +7,7 @@
 //     BuildTopLevelAccelerationStructure / CreateGeometryDesc       Source/RaytracingHelpers.ixx:28-105
 // Error behaviour: a failing status becomes the exception type the reference throws at the same place
 // (std::invalid_argument for argument checks, std::system_error otherwise: Source/ErrorHelpers.ixx:16-32).
-// Header-only, plain C++17, no HIP headers needed by the including translation unit.
+// Header-only, plain C++20 (std::span), no HIP headers needed by the including translation unit.
 #pragma once
 #include <cstdint>
 #include <span>

@@ -646,9 +646,9 @@ static void ray_setup(RayObj* r, f3 o, f3 d)
     int ky = kx + 1; if (ky == 3) ky = 0;
     if (get3(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
     r->kx = kx; r->ky = ky; r->kz = kz;
-    r->Sx = get3(d, kx) / get3(d, kz);
-    r->Sy = get3(d, ky) / get3(d, kz);
-    r->Sz = 1.0f / get3(d, kz);
+    r->Sz = 1.0f / get3(d, kz);          /* one IEEE division; Sx, Sy by multiplication (spec) */
+    r->Sx = get3(d, kx) * r->Sz;
+    r->Sy = get3(d, ky) * r->Sz;
 }
 
 /* returns 1 and (t,u,v) when the triangle is hit with t in (tmin, +inf); caller applies tmax/tie-break */
