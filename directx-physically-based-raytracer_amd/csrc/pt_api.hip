@@ -75,6 +75,7 @@ void pt_destroy(PtContext* ctx)
     for (auto& kv : c.blas) free_blas(kv.second);
     free_tlas(c.tlas);
     if (c.heapDev) hipFree(c.heapDev);
+    if (c.blobDev) hipFree(c.blobDev);
     for (int k = 0; k < 2; k++) {
         PathQueue& q = c.queue[k];
         void* ptrs[6] = { q.s0, q.s1, q.s2, q.r0, q.r1, q.hit };
@@ -186,6 +187,9 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     API_HIP(&c, hipSetDevice(c.device));
     std::vector<InstanceRecord> rec(count ? count : 1);
     std::vector<const float*> bounds(count ? count : 1);
+    std::vector<BlobPiece> pieces; std::vector<uint32_t> pieceOfInstance(count ? count : 1);
+    std::map<uint64_t, uint32_t> pieceOfBlas;
+    uint32_t blobNodes = count > 1 ? count - 1 : 1, blobTris = 0;       // TLAS nodes come first in the blob
     uint64_t tris = 0;
     for (uint32_t i = 0; i < count; i++) {
         auto it = c.blas.find(descs[i].AccelerationStructure);
@@ -199,6 +203,14 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         r.triCount = it->second.triCount; r._pad = 0;
         bounds[i] = it->second.rootBounds;
         tris += it->second.triCount;
+        auto pb = pieceOfBlas.find(descs[i].AccelerationStructure);
+        if (pb == pieceOfBlas.end()) {
+            const Blas& b = it->second;
+            pieces.push_back(BlobPiece{ b.nodes, b.tris, b.nodeCount, b.triCount, blobNodes, blobTris });
+            blobNodes += b.nodeCount; blobTris += b.triCount;
+            pb = pieceOfBlas.emplace(descs[i].AccelerationStructure, (uint32_t)pieces.size() - 1).first;
+        }
+        pieceOfInstance[i] = pb->second;
     }
     API_HIP(&c, hipStreamSynchronize(c.stream));      // nothing may still be traversing the old TLAS
     free_tlas(c.tlas); c.haveTlas = false;
@@ -209,6 +221,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     if (e == hipSuccess && count) e = hipMemcpy(t.instances, rec.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice);
     if (e == hipSuccess && count) e = hipMemcpy(dBounds, bounds.data(), sizeof(float*) * count, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = build_tlas_device(t.instances, dBounds, count, c.stream, t);
+    if (c.blobDev) { hipFree(c.blobDev); c.blobDev = nullptr; c.blob = BlobView{}; }
+    if (e == hipSuccess) e = build_blob_device(t, dBounds, pieces, pieceOfInstance, c.stream, &c.blobDev, &c.blob);
     if (dBounds) hipFree(dBounds);
     if (e != hipSuccess) { free_tlas(t); return fail_hip(&c, e, "top-level build"); }
     t.triangleCount = tris;

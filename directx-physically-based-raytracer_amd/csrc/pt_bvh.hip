@@ -406,4 +406,67 @@ fail:
     return err;
 }
 
+// ---------------------------------------------------------------------------------------------
+// compact traversal blob: [InstanceT | nodes (TLAS first) | triangle packets], see pt_trace2.hpp
+// ---------------------------------------------------------------------------------------------
+__global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const float* const* __restrict__ blasBounds,
+                                 const uint2* __restrict__ bases, uint32_t n, InstanceT* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    InstanceT t;
+    for (int k = 0; k < 12; k++) t.worldToObject[k] = inst[i].worldToObject[k];
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    const float* b = blasBounds[i];
+    const float* M = inst[i].objectToWorld;
+    if (b[0] <= b[3]) {
+        for (int c = 0; c < 8; c++) {
+            float x = (c & 1) ? b[3] : b[0], y = (c & 2) ? b[4] : b[1], z = (c & 4) ? b[5] : b[2];
+            for (int a = 0; a < 3; a++) {
+                float w = M[4 * a] * x + M[4 * a + 1] * y + M[4 * a + 2] * z + M[4 * a + 3];
+                lo[a] = fminf(lo[a], w); hi[a] = fmaxf(hi[a], w);
+            }
+        }
+    }
+    float4 l4 = make_float4(lo[0], lo[1], lo[2], 0.0f), h4 = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    pad_box(l4, h4);
+    t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = bases[i].x;
+    t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = bases[i].y;
+    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t._pad[0] = t._pad[1] = 0;
+    out[i] = t;
+}
+
+hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, const std::vector<BlobPiece>& pieces,
+                             const std::vector<uint32_t>& pieceOfInstance, hipStream_t stream, void** outDev, BlobView* outView)
+{
+    hipError_t err = hipSuccess;
+    const uint32_t n = tlas.instanceCount;
+    uint32_t nodeCount = tlas.nodeCount, triCount = 0;
+    for (const BlobPiece& p : pieces) { nodeCount += p.nodeCount; triCount += p.triCount; }
+    const size_t instBytes = (size_t)n * sizeof(InstanceT), nodeBytes = (size_t)nodeCount * sizeof(BvhNode), triBytes = (size_t)triCount * sizeof(TriPacket);
+    const size_t total = instBytes + nodeBytes + triBytes;
+    uint8_t* blob = nullptr; uint2* dBases = nullptr;
+    std::vector<uint2> bases(n ? n : 1);
+    BVH_CHECK(hipMalloc((void**)&blob, total ? total : 16));
+    BVH_CHECK(hipMalloc((void**)&dBases, sizeof(uint2) * (n ? n : 1)));
+    for (uint32_t i = 0; i < n; i++) { const BlobPiece& p = pieces[pieceOfInstance[i]]; bases[i] = make_uint2(p.nodeBase, p.triBase); }
+    if (n) BVH_CHECK(hipMemcpyAsync(dBases, bases.data(), sizeof(uint2) * n, hipMemcpyHostToDevice, stream));
+    BVH_CHECK(hipMemcpyAsync(blob + instBytes, tlas.nodes, sizeof(BvhNode) * tlas.nodeCount, hipMemcpyDeviceToDevice, stream));
+    for (const BlobPiece& p : pieces) {
+        BVH_CHECK(hipMemcpyAsync(blob + instBytes + sizeof(BvhNode) * p.nodeBase, p.nodes, sizeof(BvhNode) * p.nodeCount, hipMemcpyDeviceToDevice, stream));
+        if (p.triCount) BVH_CHECK(hipMemcpyAsync(blob + instBytes + nodeBytes + sizeof(TriPacket) * p.triBase, p.tris, sizeof(TriPacket) * p.triCount, hipMemcpyDeviceToDevice, stream));
+    }
+    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(tlas.instances, dBlasBounds, dBases, n, (InstanceT*)blob);
+    BVH_CHECK(hipGetLastError());
+    BVH_CHECK(hipStreamSynchronize(stream));
+    outView->base = (const f4v*)blob;
+    outView->instOff16 = 0; outView->nodeOff16 = (uint32_t)(instBytes / 16); outView->triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
+    outView->instCount = n; outView->nodeCount = nodeCount; outView->triCount = triCount; outView->bytes = (uint32_t)total;
+    *outDev = blob; blob = nullptr;
+fail:
+    if (blob) hipFree(blob);
+    if (dBases) hipFree(dBases);
+    return err;
+}
+
 } // namespace pt

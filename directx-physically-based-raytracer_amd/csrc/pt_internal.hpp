@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "../../include/ptamd.h"
-#include "pt_trace.hpp"
+#include "pt_trace2.hpp"
 
 namespace pt {
 
@@ -77,6 +77,8 @@ struct Context {
     const PtInstanceData* instanceData = nullptr; uint32_t instanceDataCount = 0;
     PtSharding sharding{0, 1, 16, 0};
 
+    void* blobDev = nullptr; BlobView blob{};        // compact traversal copy of TLAS + instances + every referenced BLAS
+
     PathQueue queue[2]{}; uint32_t queueCapacity = 0;
     uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;
     DeviceCounters* counters = nullptr;
@@ -91,6 +93,9 @@ struct Context {
 // pt_bvh.hip
 hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& out);
 hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out);
+struct BlobPiece { const BvhNode* nodes; const TriPacket* tris; uint32_t nodeCount, triCount, nodeBase, triBase; };
+hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, const std::vector<BlobPiece>& pieces,
+                             const std::vector<uint32_t>& pieceOfInstance, hipStream_t stream, void** outDev, BlobView* outView);
 
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);

@@ -392,6 +392,42 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q,
     }
 }
 
+// Traversal kernel (phase-aligned schedule, pt_trace2.hpp). Dynamic LDS: traversal stack (kStackLds entries
+// per lane) | candidate lists (kCandidates per lane) | the scene blob when it fits (LDS = true).
+constexpr int kStackLds2 = 16;
+constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u;
+constexpr uint32_t kBlobLdsMax = 40u * 1024u;
+
+template <bool STATS, bool LDS>
+__global__ __launch_bounds__(256) void k_extend2(BlobView bv, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t n = count[sq];
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
+    if (bq * 256u >= n) return;                                   // block-uniform: nothing to do, skip the staging
+    int* ldsStack = (int*)smem;
+    uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
+    BlobReader<LDS> blob;
+    if constexpr (LDS) {
+        f4v* dst = (f4v*)(smem + kExtendLdsFixed);
+        const uint32_t n16 = bv.bytes / 16u;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = bv.base[i];
+        __syncthreads();
+        blob.p = (const PT_LDS_AS f4v*)(smem + kExtendLdsFixed);
+    } else {
+        blob.p = bv.base;
+    }
+    TraceStats st; st.nodes = 0; st.tris = 0;
+    for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
+        const uint32_t i = sq * segCap + local;
+        const float4 o = q.r0[i], d = q.r1[i];
+        const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
+        q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+    }
+    if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
@@ -497,9 +533,19 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
+        const bool lds = c.blob.bytes <= kBlobLdsMax;
+        const uint32_t smem = kExtendLdsFixed + (lds ? c.blob.bytes : 0u);
         if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
-        else if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
-        else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+        else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
+            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+            else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+        } else if (lds) {
+            if (stats) k_extend2<true, true><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+            else k_extend2<false, true><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+        } else {
+            if (stats) k_extend2<true, false><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+            else k_extend2<false, false><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+        }
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }
     c.lastIterations = rounds + 1;
