@@ -75,6 +75,7 @@ void pt_destroy(PtContext* ctx)
     for (auto& kv : c.blas) free_blas(kv.second);
     free_tlas(c.tlas);
     if (c.heapDev) hipFree(c.heapDev);
+    if (c.srgbLutDev) hipFree(c.srgbLutDev);
     if (c.blobDev) hipFree(c.blobDev);
     for (int k = 0; k < 2; k++) {
         PathQueue& q = c.queue[k];
@@ -120,15 +121,36 @@ int pt_heap_set_buffer(PtContext* ctx, uint32_t descriptor, const void* device_p
     Context& c = ctx->c;
     API_ARG(&c, descriptor < c.heapHost.size(), "descriptor index beyond pt_heap_resize");
     API_ARG(&c, stride == 0 || stride == 2 || stride == 4, "typed buffer stride must be 0 (raw), 2 or 4");
-    c.heapHost[descriptor] = HeapEntry{ device_ptr, bytes, stride, 0 };
+    c.heapHost[descriptor] = HeapEntry{ device_ptr, bytes, stride, kKindBuffer };
+    c.heapDirty = true;
+    return PT_OK;
+}
+
+int pt_heap_set_texture(PtContext* ctx, uint32_t descriptor, const void* device_ptr, uint32_t width, uint32_t height, uint32_t format, uint32_t is_cube)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_ARG(&c, descriptor < c.heapHost.size(), "descriptor index beyond pt_heap_resize");
+    API_ARG(&c, device_ptr && width && height, "texture pointer / size is null");
+    API_ARG(&c, format <= PT_FORMAT_R32G32B32A32_FLOAT, "unsupported texture format");
+    API_ARG(&c, !is_cube || width == height, "cube faces must be square");
+    c.heapHost[descriptor] = HeapEntry{ device_ptr, (uint64_t)width | ((uint64_t)height << 32), format, is_cube ? kKindTextureCube : kKindTexture2D };
     c.heapDirty = true;
     return PT_OK;
 }
 
 static int upload_heap(Context& c)
 {
+    if (!c.srgbLutDev) {                                  // sRGB -> linear table, evaluated in double (arithmetic spec)
+        float lut[256];
+        for (int i = 0; i < 256; i++) { double v = i / 255.0; lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4)); }
+        API_HIP(&c, hipMalloc((void**)&c.srgbLutDev, sizeof lut));
+        API_HIP(&c, hipMemcpy(c.srgbLutDev, lut, sizeof lut, hipMemcpyHostToDevice));
+    }
     if (!c.heapDirty) return PT_OK;
     uint32_t n = (uint32_t)c.heapHost.size();
+    c.heapHasTextures = false;
+    for (const HeapEntry& e : c.heapHost) if (e.kind != kKindBuffer) c.heapHasTextures = true;
     if (n > c.heapDevCap) {
         if (c.heapDev) hipFree(c.heapDev);
         c.heapDev = nullptr; c.heapDevCap = 0;
@@ -324,6 +346,7 @@ static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv
     sv.objects = c.objects; sv.objectCount = c.objectCount;
     sv.instanceData = c.instanceData;
     sv.heap = c.heapDev; sv.heapCount = (uint32_t)c.heapHost.size();
+    sv.srgbLut = c.srgbLutDev;
     fv.width = width; fv.height = height;
     fv.rankIndex = c.sharding.RankIndex; fv.rankCount = c.sharding.RankCount; fv.bandHeight = c.sharding.BandHeight;
     pt_local_rows(&c.sharding, height, &fv.localRows);

@@ -27,7 +27,6 @@ struct Tlas {
     uint64_t triangleCount = 0;              // sum over instances
 };
 
-struct HeapEntry { const void* ptr; uint64_t bytes; uint32_t stride; uint32_t _pad; };   // device copy is the same struct
 
 // everything a render kernel needs about the scene, passed by value as a kernel argument
 struct SceneView {
@@ -35,6 +34,7 @@ struct SceneView {
     const PtObjectData* objects;
     const PtInstanceData* instanceData;
     const HeapEntry* heap;
+    const float* srgbLut;                    // 256-entry sRGB -> linear table (device)
     uint32_t objectCount, heapCount;
 };
 
@@ -67,6 +67,8 @@ struct Context {
 
     std::vector<HeapEntry> heapHost;
     HeapEntry* heapDev = nullptr; uint32_t heapDevCap = 0; bool heapDirty = true;
+    float* srgbLutDev = nullptr;
+    bool heapHasTextures = false;             // any Texture2D / TextureCube descriptor: selects the TEXTURED kernel variants
 
     std::map<uint64_t, Blas> blas; uint64_t nextBlasId = 1;
     Tlas tlas; bool haveTlas = false;

@@ -43,9 +43,18 @@ PT_DEV uint32_t global_row(const FrameView& fv, uint32_t localRow)
     return (band * fv.rankCount + fv.rankIndex) * fv.bandHeight + within;
 }
 
-// GetEnvironmentLightColor (Shaders/ShadingHelpers.hlsli:11-30); environment textures are "next" 
-PT_DEV v3 environment_light_color(const PtSceneData& sd, v3 dir)
+// GetEnvironmentLightColor (Shaders/ShadingHelpers.hlsli:11-30)
+PT_DEV v3 environment_light_color(const SceneView& sv, const PtSceneData& sd, v3 dir)
 {
+    if (sd.EnvironmentLightTextureDescriptor != ~0u) {
+        const float* M = sd.EnvironmentLightTransform;
+        const v3 w = normalize(V3(M[0] * dir.x + M[1] * dir.y + M[2] * dir.z, M[4] * dir.x + M[5] * dir.y + M[6] * dir.z, M[8] * dir.x + M[9] * dir.y + M[10] * dir.z));
+        const HeapEntry t = sv.heap[sd.EnvironmentLightTextureDescriptor];
+        f4 c;
+        if (sd.IsEnvironmentLightTextureCubeMap) c = cube_sample(t, sv.srgbLut, w);
+        else c = texture_sample(t, sv.srgbLut, (1.0f + atan2f(w.x, w.z) / kPi) / 2.0f, acosf(w.y) / kPi);   // Math::ToLatLongCoordinate, Math.hlsli:29-33
+        return V3(c.x, c.y, c.z);
+    }
     if (sd.EnvironmentLightColor[3] >= 0.0f) return V3(sd.EnvironmentLightColor);
     float t = (dir.y + 1.0f) * 0.5f;
     return V3(ml_from_srgb1(1.0f + t * (0.5f - 1.0f)), ml_from_srgb1(1.0f + t * (0.7f - 1.0f)), ml_from_srgb1(1.0f + t * (1.0f - 1.0f)));
@@ -59,10 +68,17 @@ PT_DEV void xform4(const float* M, v3 p, float out[4])
 
 struct SurfaceHit {               // the part of HitInfo (Shaders/HitInfo.hlsli:7-22) this path consumes
     v3 Position, ObjectPosition; float PositionOffset;
-    v3 FlatNormal, GeometricNormal, ShadingNormal;
+    v3 FlatNormal, GeometricNormal, ShadingNormal, Tangent;
     bool IsFrontFace;
+    TexCoords TextureCoordinates;
     uint32_t InstanceIndex, ObjectIndex, PrimitiveIndex;
 };
+
+PT_DEV AlphaContext alpha_context(const SceneView& sv)
+{
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    return ac;
+}
 
 PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)      // MeshHelpers.hlsli:5-9 (typed R16/R32 buffer)
 {
@@ -72,6 +88,9 @@ PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)     
 // Hit reconstruction half of CastRay (Shaders/RaytracingHelpers.hlsli:73-131) + HitInfo::Initialize
 // (Shaders/HitInfo.hlsli:24-65). Positions come from the BLAS triangle packet (bit-identical copies of the
 // vertex-buffer positions); normals from the vertex buffer through the descriptor heap.
+// TEXTURED = false (no texture descriptor exists in the heap): tangents, UVs and the TextureMapInfo half of
+// ObjectData are never fetched.
+template <bool TEXTURED>
 PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot, float bu, float bv, v3 rayDir, SurfaceHit& h)
 {
     const InstanceRecord* ir = &sv.accel.instances[inst];
@@ -108,14 +127,39 @@ PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot
     h.ShadingNormal = h.GeometricNormal;
     h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
     if (!h.IsFrontFace) h.ShadingNormal = -h.ShadingNormal;
+    h.Tangent = V3(0.0f, 0.0f, 0.0f);                      // RaytracingHelpers.hlsli:115-122
+    if (!TEXTURED) return;
+    const uint32_t tOff = od->VertexDesc.AttributeOffsets.Tangent;
+    if (tOff != ~0u) {
+        const HeapEntry vb = sv.heap[od->MeshDescriptors.Vertices], ib = sv.heap[od->MeshDescriptors.Indices];
+        const uint32_t stride = od->VertexDesc.Stride;
+        v3 tg[3];
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
+            const int16_t* q = (const int16_t*)((const uint8_t*)vb.ptr + (size_t)stride * idx + tOff);
+            tg[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
+        }
+        const v3 t = (tg[0] + (tg[1] - tg[0]) * bu) + (tg[2] - tg[0]) * bv;
+        h.Tangent = normalize(V3(M[0] * t.x + M[1] * t.y + M[2] * t.z, M[4] * t.x + M[5] * t.y + M[6] * t.z, M[8] * t.x + M[9] * t.y + M[10] * t.z));
+    }
+    get_texture_coordinates(od, sv.heap, prim, bu, bv, h.TextureCoordinates);      // :124-130
 }
 
 PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
 
+template <bool TEXTURED>
+PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
+{
+    if (!TEXTURED) return sv.objects[h.ObjectIndex].Material;           // EvaluateMaterial with every Descriptor == ~0u
+    return evaluate_material(h.ShadingNormal, h.IsFrontFace ? h.Tangent : -h.Tangent, &sv.objects[h.ObjectIndex], sv.heap, sv.srgbLut,
+                             h.TextureCoordinates);                       // ShadingHelpers.hlsli:161-235
+}
+
 // ---------------------------------------------------------------------------------------------
 // G-buffer (Shaders/GBufferGeneration.hlsl:116-232). One thread per local pixel, 16x16 tiles.
 // ---------------------------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool TEXTURED>
 __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, uint32_t flags, PtTextures tx,
                                                  DeviceCounters* counters)
 {
@@ -132,12 +176,12 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
     int spill[kStackSize - kLdsStackDepth];
     TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
     TraceStats st; st.nodes = 0; st.tris = 0;
-    const Hit hit = trace_closest<STATS>(sv.accel, ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
+    const Hit hit = trace_closest<STATS>(sv.accel, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 
     if (hit.inst != ~0u) {
         SurfaceHit h;
-        reconstruct_hit(sv, hit.inst, hit.slot, hit.u, hit.v, ray.d, h);
+        reconstruct_hit<TEXTURED>(sv, hit.inst, hit.slot, hit.u, hit.v, ray.d, h);
         if (flags & PT_GB_Geometry) {
             Position = make_float4(h.Position.x, h.Position.y, h.Position.z, h.PositionOffset);
             float ex, ey;
@@ -168,7 +212,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
         }
         BSDFSample bs; bs.Roughness = 0.0f;
         if (flags & PT_GB_Material) {
-            const PtMaterial m = sv.objects[h.ObjectIndex].Material;      // EvaluateMaterial, untextured (ShadingHelpers.hlsli:161-235)
+            const PtMaterial m = surface_material<TEXTURED>(sv, h);
             bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
             if (tx.BaseColorMetalness)
                 ((uchar4*)tx.BaseColorMetalness)[pi] = make_uchar4(f32_to_unorm8(bs.BaseColor.x), f32_to_unorm8(bs.BaseColor.y), f32_to_unorm8(bs.BaseColor.z), f32_to_unorm8(bs.Metallic));
@@ -194,7 +238,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
             ((ushort4*)tx.MotionVector)[pi] = make_ushort4(f32_to_f16((su - u) * (float)fv.width), f32_to_f16((svv - v) * (float)fv.height), f32_to_f16(view[2] - proj[3]), 0);
         }
         if ((flags & PT_GB_Radiance) && tx.Radiance) {
-            v3 e = environment_light_color(sd, ray.d);
+            v3 e = environment_light_color(sv, sd, ray.d);
             ((ushort4*)tx.Radiance)[pi] = make_ushort4(f32_to_f16(e.x), f32_to_f16(e.y), f32_to_f16(e.z), 0);
         }
     }
@@ -253,6 +297,7 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSetting
     }
 }
 
+template <bool TEXTURED>
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, PtGraphicsSettings gs, PtTextures tx,
                                                PathQueue qin, PathQueue qout, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
@@ -285,11 +330,11 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCam
                     const float4 rd = qin.r1[i];
                     rayDir = V3(rd.x, rd.y, rd.z);
                     if (hr.x == ~0u) {                                     // :241-259
-                        srad = srad + thr * environment_light_color(sd, rayDir);
+                        srad = srad + thr * environment_light_color(sv, sd, rayDir);
                         isHit = false;
                     } else {                                               // :293-304
-                        reconstruct_hit(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
-                        const PtMaterial m = sv.objects[h.ObjectIndex].Material;
+                        reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+                        const PtMaterial m = surface_material<TEXTURED>(sv, h);
                         emission = material_emission(m);
                         bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
                     }
@@ -366,7 +411,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCam
     }
 }
 
-__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
@@ -378,8 +423,8 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, PathQueue q,
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
-        const Hit h = trace_brute_force(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w);
-        const Hit b = trace_closest<false>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        const Hit h = trace_brute_force(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w);
+        const Hit b = trace_closest<false>(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
         if (b.inst != h.inst || (h.inst != ~0u && (b.slot != h.slot || b.u != h.u || b.v != h.v))) {
             if (atomicAdd(&counters->mismatchCount, 1u) == 0u) {
                 float* m = counters->mismatchRay;
@@ -399,7 +444,7 @@ constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
 template <bool STATS, bool LDS>
-__global__ __launch_bounds__(256) void k_extend2(BlobView bv, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
@@ -422,14 +467,14 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, PathQueue q, uint3
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
-        const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
+        const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend(AccelView av, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
@@ -441,7 +486,7 @@ __global__ __launch_bounds__(256) void k_extend(AccelView av, PathQueue q, uint3
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
-        const Hit h = trace_closest<STATS>(av, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        const Hit h = trace_closest<STATS>(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
@@ -476,8 +521,14 @@ hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, 
 {
     if (fv.localRows == 0 || fv.width == 0) return hipSuccess;
     dim3 grid((fv.width + 15) / 16, (fv.localRows + 15) / 16);
-    if (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) k_gbuffer<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
-    else k_gbuffer<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+    const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
+    if (c.heapHasTextures) {
+        if (stats) k_gbuffer<true, true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+        else k_gbuffer<false, true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+    } else {
+        if (stats) k_gbuffer<true, false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+        else k_gbuffer<false, false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
+    }
     k_count_primary<<<1, 1, 0, c.stream>>>(c.counters, (unsigned long long)fv.width * fv.localRows);
     return hipGetLastError();
 }
@@ -525,26 +576,28 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     const uint32_t grid = persistent_grid(c.device);
     k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], segCap, &c.queueCounts[0]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         timing_begin(c, c.evShade, c.nShade);
         uint32_t* cin = &c.queueCounts[r * kSubQueues]; uint32_t* cout = &c.queueCounts[(r + 1) * kSubQueues];
-        k_shade<<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
+        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
+        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const uint32_t smem = kExtendLdsFixed + (lds ? c.blob.bytes : 0u);
-        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
         else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
-            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
-            else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, qout, segCap, cout, c.counters);
+            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
+            else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
         } else if (lds) {
-            if (stats) k_extend2<true, true><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
-            else k_extend2<false, true><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+            if (stats) k_extend2<true, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            else k_extend2<false, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
         } else {
-            if (stats) k_extend2<true, false><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
-            else k_extend2<false, false><<<grid, 256, smem, c.stream>>>(c.blob, qout, segCap, cout, c.counters);
+            if (stats) k_extend2<true, false><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            else k_extend2<false, false><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
         }
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }

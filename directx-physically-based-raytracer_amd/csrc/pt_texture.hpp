@@ -1,0 +1,162 @@
+// pt_texture.hpp -- texture taps and material evaluation (device code, gfx950).
+//
+//   Sample<T> / EvaluateBaseColor / EvaluateTransmission / PerturbNormal / IsOpaque / EvaluateMaterial
+//       Shaders/ShadingHelpers.hlsli:53-235
+//   GetTextureCoordinates  Shaders/ShadingHelpers.hlsli:32-51
+// Every tap is SampleLevel(g_anisotropicSampler, uv, 0) with the root-signature default static sampler
+// (Shaders/Raytracing.hlsl:79): WRAP addressing, mip 0, bilinear. [spec] fp32 weights, sRGB decoded per
+// texel through a 256-entry table built on the host in double precision (DESIGN.md "Arithmetic spec").
+#pragma once
+#include "pt_math.hpp"
+#include "../../include/ptamd.h"
+
+namespace pt {
+
+struct HeapEntry { const void* ptr; uint64_t bytes; uint32_t stride; uint32_t kind; };   // textures: bytes = w | h << 32, stride = format
+enum : uint32_t { kKindBuffer = 0, kKindTexture2D = 1, kKindTextureCube = 2 };
+enum : uint32_t { kFmtRGBA8 = 0, kFmtRGBA8Srgb = 1, kFmtRGBA32F = 2 };
+
+struct f4 { float x, y, z, w; };
+
+PT_DEV f4 texel_fetch(const HeapEntry& t, const float* srgbLut, uint32_t face, uint32_t x, uint32_t y)
+{
+    const uint32_t W = (uint32_t)(t.bytes & 0xFFFFFFFFu), H = (uint32_t)(t.bytes >> 32);
+    const size_t idx = ((size_t)face * H + y) * W + x;
+    f4 o;
+    if (t.stride == kFmtRGBA32F) {
+        const float4 v = ((const float4*)t.ptr)[idx];
+        o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+        return o;
+    }
+    const uchar4 p = ((const uchar4*)t.ptr)[idx];
+    if (t.stride == kFmtRGBA8Srgb) { o.x = srgbLut[p.x]; o.y = srgbLut[p.y]; o.z = srgbLut[p.z]; }
+    else { o.x = unorm8_to_f32(p.x); o.y = unorm8_to_f32(p.y); o.z = unorm8_to_f32(p.z); }
+    o.w = unorm8_to_f32(p.w);
+    return o;
+}
+
+PT_DEV f4 bilinear(const HeapEntry& t, const float* srgbLut, uint32_t face, float fx, float fy, bool wrap)
+{
+    const int W = (int)(t.bytes & 0xFFFFFFFFu), H = (int)(t.bytes >> 32);
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const float wx = fx - x0f, wy = fy - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    if (wrap) {
+        x0 = ((x0 % W) + W) % W; x1 = ((x1 % W) + W) % W; y0 = ((y0 % H) + H) % H; y1 = ((y1 % H) + H) % H;
+    } else {
+        x0 = x0 < 0 ? 0 : (x0 >= W ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= W ? W - 1 : x1);
+        y0 = y0 < 0 ? 0 : (y0 >= H ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= H ? H - 1 : y1);
+    }
+    const f4 c00 = texel_fetch(t, srgbLut, face, (uint32_t)x0, (uint32_t)y0), c10 = texel_fetch(t, srgbLut, face, (uint32_t)x1, (uint32_t)y0);
+    const f4 c01 = texel_fetch(t, srgbLut, face, (uint32_t)x0, (uint32_t)y1), c11 = texel_fetch(t, srgbLut, face, (uint32_t)x1, (uint32_t)y1);
+    f4 o;
+    { float top = c00.x * (1.0f - wx) + c10.x * wx, bot = c01.x * (1.0f - wx) + c11.x * wx; o.x = top * (1.0f - wy) + bot * wy; }
+    { float top = c00.y * (1.0f - wx) + c10.y * wx, bot = c01.y * (1.0f - wx) + c11.y * wx; o.y = top * (1.0f - wy) + bot * wy; }
+    { float top = c00.z * (1.0f - wx) + c10.z * wx, bot = c01.z * (1.0f - wx) + c11.z * wx; o.z = top * (1.0f - wy) + bot * wy; }
+    { float top = c00.w * (1.0f - wx) + c10.w * wx, bot = c01.w * (1.0f - wx) + c11.w * wx; o.w = top * (1.0f - wy) + bot * wy; }
+    return o;
+}
+
+PT_DEV f4 texture_sample(const HeapEntry& t, const float* srgbLut, float u, float v)
+{
+    const float W = (float)(uint32_t)(t.bytes & 0xFFFFFFFFu), H = (float)(uint32_t)(t.bytes >> 32);
+    if (!(u == u) || !isfinite(u)) u = 0.0f;
+    if (!(v == v) || !isfinite(v)) v = 0.0f;
+    u = u - floorf(u); v = v - floorf(v);
+    return bilinear(t, srgbLut, 0, u * W - 0.5f, v * H - 0.5f, true);
+}
+
+PT_DEV f4 cube_sample(const HeapEntry& t, const float* srgbLut, v3 d)
+{
+    const float W = (float)(uint32_t)(t.bytes & 0xFFFFFFFFu), H = (float)(uint32_t)(t.bytes >> 32);
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    float sc, tc, ma; uint32_t face;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az) { ma = ay; if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+    else { ma = az; if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    const float u = (sc / ma + 1.0f) * 0.5f, v = (tc / ma + 1.0f) * 0.5f;
+    return bilinear(t, srgbLut, face, u * W - 0.5f, v * H - 0.5f, false);
+}
+
+struct TexCoords { float uv[2][2]; };
+
+PT_DEV f4 sample_map(const HeapEntry* heap, const float* srgbLut, const PtTextureMapInfo& info, const TexCoords& tc)
+{
+    const float* c = tc.uv[info.TextureCoordinateIndex & 1u];
+    return texture_sample(heap[info.Descriptor], srgbLut, c[0], c[1]);
+}
+
+enum : int { TEX_BaseColor = 0, TEX_EmissiveColor, TEX_Metallic, TEX_Roughness, TEX_MetallicRoughness, TEX_Transmission, TEX_Normal };
+
+PT_DEV uint32_t load_index_tex(const void* ib, uint32_t stride, uint32_t i)
+{
+    return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
+}
+
+// GetTextureCoordinates, ShadingHelpers.hlsli:32-51
+PT_DEV void get_texture_coordinates(const PtObjectData* od, const HeapEntry* heap, uint32_t prim, float bu, float bv, TexCoords& tc)
+{
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        tc.uv[i][0] = tc.uv[i][1] = 0.0f;
+        const uint32_t off = od->VertexDesc.AttributeOffsets.TextureCoordinates[i];
+        if (off == ~0u) continue;
+        const HeapEntry vb = heap[od->MeshDescriptors.Vertices], ib = heap[od->MeshDescriptors.Indices];
+        float a[3][2];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t idx = load_index_tex(ib.ptr, ib.stride, 3 * prim + k);
+            const uint16_t* h = (const uint16_t*)((const uint8_t*)vb.ptr + (size_t)od->VertexDesc.Stride * idx + off);
+            a[k][0] = f16_to_f32(h[0]); a[k][1] = f16_to_f32(h[1]);
+        }
+        for (int c = 0; c < 2; c++) tc.uv[i][c] = a[0][c] + bu * (a[1][c] - a[0][c]) + bv * (a[2][c] - a[0][c]);
+    }
+}
+
+// IsOpaque (closest-hit overload), ShadingHelpers.hlsli:105-115
+PT_DEV bool is_opaque(const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc)
+{
+    float a = od->Material.BaseColor[3];
+    const PtTextureMapInfo& info = od->TextureMapInfoArray[TEX_BaseColor];
+    const float* bc = od->Material.BaseColor;
+    if ((bc[0] > 0.0f || bc[1] > 0.0f || bc[2] > 0.0f || bc[3] > 0.0f) && info.Descriptor != ~0u) a *= sample_map(heap, srgbLut, info, tc).w;
+    return a >= od->Material.AlphaCutoff;
+}
+
+// EvaluateMaterial, ShadingHelpers.hlsli:161-235. N: shading normal (in/out), T: front tangent.
+PT_DEV PtMaterial evaluate_material(v3& N, v3 T, const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc)
+{
+    PtMaterial m = od->Material;
+    const PtTextureMapInfo* ti = od->TextureMapInfoArray;
+    if ((m.BaseColor[0] > 0.0f || m.BaseColor[1] > 0.0f || m.BaseColor[2] > 0.0f || m.BaseColor[3] > 0.0f) && ti[TEX_BaseColor].Descriptor != ~0u) {
+        const f4 t = sample_map(heap, srgbLut, ti[TEX_BaseColor], tc);
+        m.BaseColor[0] *= t.x; m.BaseColor[1] *= t.y; m.BaseColor[2] *= t.z; m.BaseColor[3] *= t.w;
+    }
+    const v3 em = V3(m.EmissiveColor) * m.EmissiveStrength;
+    if ((em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) && ti[TEX_EmissiveColor].Descriptor != ~0u) {
+        const f4 t = sample_map(heap, srgbLut, ti[TEX_EmissiveColor], tc);
+        m.EmissiveColor[0] *= t.x; m.EmissiveColor[1] *= t.y; m.EmissiveColor[2] *= t.z;
+    }
+    if (ti[TEX_MetallicRoughness].Descriptor != ~0u) {
+        if (m.Metallic > 0.0f || m.Roughness > 0.0f) {
+            const f4 t = sample_map(heap, srgbLut, ti[TEX_MetallicRoughness], tc);
+            m.Metallic *= t.z; m.Roughness *= t.y;
+        }
+    } else {
+        if (m.Metallic > 0.0f && ti[TEX_Metallic].Descriptor != ~0u) m.Metallic *= sample_map(heap, srgbLut, ti[TEX_Metallic], tc).x;
+        if (m.Roughness > 0.0f && ti[TEX_Roughness].Descriptor != ~0u) m.Roughness *= sample_map(heap, srgbLut, ti[TEX_Roughness], tc).x;
+    }
+    if (m.Metallic < 1.0f) {
+        if (m.Transmission > 0.0f && ti[TEX_Transmission].Descriptor != ~0u) m.Transmission *= sample_map(heap, srgbLut, ti[TEX_Transmission], tc).x;
+    }
+    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && ti[TEX_Normal].Descriptor != ~0u) {        // PerturbNormal :89-103
+        const f4 t = sample_map(heap, srgbLut, ti[TEX_Normal], tc);
+        const float nx = t.x * 2.0f - 1.0f, ny = t.y * 2.0f - 1.0f;                                 // [MathLib] Geometry::UnpackLocalNormal
+        const float nz = ml_sqrt01(1.0f - (nx * nx + ny * ny));
+        const v3 Tn = normalize(T - N * dot(N, T));                                                 // Math::CalculateTBN, Math.hlsli:17-21
+        const v3 B = cross(N, Tn);
+        N = normalize(V3(Tn.x * nx + B.x * ny + N.x * nz, Tn.y * nx + B.y * ny + N.y * nz, Tn.z * nx + B.z * ny + N.z * nz));
+    }
+    return m;
+}
+
+} // namespace pt

@@ -13,7 +13,7 @@
 // Triangle packet (48 B): v0.xyz geom | v1.xyz prim | v2.xyz flags  -- object-space positions in
 // Morton order so a leaf's triangles are contiguous.
 #pragma once
-#include "pt_math.hpp"
+#include "pt_texture.hpp"
 
 namespace pt {
 
@@ -123,15 +123,38 @@ PT_DEV bool tri_test(const RaySetup& r, v3 o, v3 v0, v3 v1, v3 v2, float& t, flo
 
 // Closest hit with ties on t broken by (instance, geometry, primitive) so the result does not
 // depend on traversal order. Triangle hits are accepted for t in (tmin, tmax) exclusive.
+PT_DEV bool is_better(const Hit& h, float tmin, float t, uint32_t inst, uint32_t geom, uint32_t prim)
+{
+    if (!(t > tmin)) return false;
+    if (t < h.t) return true;
+    if (t == h.t && h.inst != ~0u)
+        return inst < h.inst || (inst == h.inst && (geom < h.geom || (geom == h.geom && prim < h.prim)));
+    return false;
+}
 PT_DEV void commit(Hit& h, float tmin, float t, float u, float v, uint32_t inst, uint32_t geom, uint32_t prim, uint32_t slot)
 {
-    if (!(t > tmin)) return;
-    bool better;
-    if (t < h.t) better = true;
-    else if (t == h.t && h.inst != ~0u)
-        better = inst < h.inst || (inst == h.inst && (geom < h.geom || (geom == h.geom && prim < h.prim)));
-    else better = false;
-    if (better) { h.t = t; h.u = u; h.v = v; h.inst = inst; h.geom = geom; h.prim = prim; h.slot = slot; }
+    if (is_better(h, tmin, t, inst, geom, prim)) { h.t = t; h.u = u; h.v = v; h.inst = inst; h.geom = geom; h.prim = prim; h.slot = slot; }
+}
+
+// What the non-opaque candidate callback needs (TraceRay, Shaders/RaytracingHelpers.hlsli:19-44): the object
+// table, the descriptor heap and the instance table (InstanceID). nullptr members = no alpha-tested geometry.
+struct AlphaContext {
+    const PtObjectData* objects;
+    const HeapEntry* heap;
+    const float* srgbLut;
+    const struct InstanceRecord* instances;
+};
+
+PT_DEV bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
+
+// commit() for a candidate of a geometry without D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE: the alpha test runs only
+// for candidates that would otherwise be committed (DXR reports candidates inside the current ray interval).
+PT_DEV void commit_candidate(const AlphaContext& ac, uint32_t flags, Hit& h, float tmin, float t, float u, float v,
+                             uint32_t inst, uint32_t geom, uint32_t prim, uint32_t slot)
+{
+    if (!is_better(h, tmin, t, inst, geom, prim)) return;
+    if (!(flags & PT_GEOMETRY_FLAG_OPAQUE) && !candidate_is_opaque(ac, inst, geom, prim, u, v)) return;
+    h.t = t; h.u = u; h.v = v; h.inst = inst; h.geom = geom; h.prim = prim; h.slot = slot;
 }
 
 // slab test against the two child boxes of a node; conservative: NaN slabs are ignored
@@ -164,8 +187,16 @@ PT_DEV float safe_inv1(float d)
 PT_DEV v3 safe_inv(v3 d) { return V3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
 
 // TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
+PT_DEV bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
+{
+    const PtObjectData* od = &ac.objects[ac.instances[inst].instanceID + geom];
+    TexCoords tc;
+    get_texture_coordinates(od, ac.heap, prim, u, v, tc);
+    return is_opaque(od, ac.heap, ac.srgbLut, tc);
+}
+
 template <bool STATS, typename STACK>
-PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax, STACK& stack, TraceStats* stats)
+PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax, STACK& stack, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     if (av.instanceCount == 0) return h;
@@ -230,7 +261,7 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
                 if (STATS) stats->tris++;
                 float t, u, v;
                 if (tri_test(rs, ro, V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), t, u, v))
-                    commit(h, tmin, t, u, v, curInst, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), first + i);
+                    commit_candidate(ac, __float_as_uint(tp.c.w), h, tmin, t, u, v, curInst, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), first + i);
             }
         }
         cur = stack.pop();
@@ -240,7 +271,7 @@ PT_DEV Hit trace_closest(const AccelView& av, v3 o, v3 d, float tmin, float tmax
 }
 
 // Debug / validation traversal (PT_DEBUG_BRUTE_FORCE): every triangle of every instance, no BVH.
-PT_DEV Hit trace_brute_force(const AccelView& av, v3 o, v3 d, float tmin, float tmax)
+PT_DEV Hit trace_brute_force(const AccelView& av, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     for (uint32_t x = 0; x < av.instanceCount; x++) {
@@ -258,7 +289,7 @@ PT_DEV Hit trace_brute_force(const AccelView& av, v3 o, v3 d, float tmin, float 
             const TriPacket tp = ir->tris[i];
             float t, u, v;
             if (tri_test(rs, ro, V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), t, u, v))
-                commit(h, tmin, t, u, v, x, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), i);
+                commit_candidate(ac, __float_as_uint(tp.c.w), h, tmin, t, u, v, x, __float_as_uint(tp.a.w), __float_as_uint(tp.b.w), i);
         }
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;

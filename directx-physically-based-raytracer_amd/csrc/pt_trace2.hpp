@@ -63,7 +63,7 @@ PT_DEV void node_test_v(f4v c0xy, f4v c1xy, f4v cz, v3 idir, v3 ood, float tmin,
 
 // lane-private views of the LDS scratch: entry e of thread t at base[e * 256 + t]
 template <bool STATS, bool LDS, int STACK_DEPTH>
-PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, v3 o, v3 d, float tmin, float tmax,
+PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
                             int* ldsStack, uint32_t* ldsCand, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
@@ -157,7 +157,7 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, v3 
                     if (STATS) stats->tris++;
                     float t, u, v;
                     if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                        commit(h, tmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
+                        commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
                 }
                 c = stack.pop();
             }

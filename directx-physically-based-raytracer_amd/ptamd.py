@@ -20,7 +20,7 @@ _LIB = None
 
 EXPORTS = [
     "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync",
-    "pt_heap_resize", "pt_heap_set_buffer", "pt_build_bottom_level", "pt_release_bottom_level",
+    "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_release_bottom_level",
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_reset_counters", "pt_get_counters",
@@ -89,6 +89,7 @@ def load_library():
         lib.pt_sync.argtypes = [C.c_void_p]
         lib.pt_heap_resize.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_heap_set_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
+        lib.pt_heap_set_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.pt_build_bottom_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.pt_release_bottom_level.argtypes = [C.c_void_p, C.c_uint64]
         lib.pt_build_top_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -216,10 +217,14 @@ class Scene:
         self._buffers = []
         ctx.check(lib.pt_heap_resize(ctx.handle, len(scene.heap)))
         heap_dev = []
-        for i, (arr, stride) in enumerate(scene.heap):
-            t = to_device(arr, self.device)
+        for i, item in enumerate(scene.heap):
+            t = to_device(item.array, self.device)
             self._buffers.append(t); heap_dev.append(t)
-            ctx.check(lib.pt_heap_set_buffer(ctx.handle, i, C.c_void_p(t.data_ptr()), arr.nbytes, stride))
+            if item.kind == 0:
+                ctx.check(lib.pt_heap_set_buffer(ctx.handle, i, C.c_void_p(t.data_ptr()), item.array.nbytes, item.stride))
+            else:
+                ctx.check(lib.pt_heap_set_texture(ctx.handle, i, C.c_void_p(t.data_ptr()), item.width, item.height, item.fmt,
+                                                  1 if item.kind == 2 else 0))
         self.object_data = to_device(scene.object_data, self.device)
         self.instance_data = to_device(scene.instance_data, self.device)
         ctx.check(lib.pt_set_object_data(ctx.handle, C.c_void_p(self.object_data.data_ptr()), len(scene.object_data)))

@@ -24,13 +24,17 @@ def encode_snorm16(v):
     return np.where(v >= 0, np.floor(v + 0.5), np.ceil(v - 0.5)).astype(np.int16)
 
 
-def make_vertices(positions, normals=None, uvs=None):
+def make_vertices(positions, normals=None, uvs=None, tangents=None, uvs1=None):
     vb = np.zeros(len(positions), L.VERTEX)
     vb["Position"] = np.asarray(positions, np.float32)
     if normals is not None:
         vb["Normal"] = encode_snorm16(normals)
+    if tangents is not None:
+        vb["Tangent"] = encode_snorm16(tangents)
     if uvs is not None:
         vb["TexCoord0"] = np.asarray(uvs, np.float16)
+    if uvs1 is not None:
+        vb["TexCoord1"] = np.asarray(uvs1, np.float16)
     return vb
 
 
@@ -40,12 +44,44 @@ def make_indices(idx):
     return idx.astype(np.uint16 if idx.size <= 65535 else np.uint32)
 
 
+FMT_RGBA8_UNORM, FMT_RGBA8_UNORM_SRGB, FMT_RGBA32_FLOAT = 0, 1, 2
+KIND_BUFFER, KIND_TEXTURE2D, KIND_TEXTURECUBE = 0, 1, 2
+TEX_SLOTS = ["BaseColor", "EmissiveColor", "Metallic", "Roughness", "MetallicRoughness", "Transmission", "Normal"]   # Material.ixx:22-33
+
+
+@dataclass
+class Texture:
+    """Mip 0 of a texture. data: [H,W,4] (2D) or [6,H,W,4] (cube, faces +X,-X,+Y,-Y,+Z,-Z); uint8 or float32.
+    srgb: base-colour / emissive textures are created as *_UNORM_SRGB (Source/GLTFHelpers.ixx:375-391)."""
+    data: np.ndarray
+    srgb: bool = False
+
+    @property
+    def fmt(self):
+        if self.data.dtype == np.float32:
+            return FMT_RGBA32_FLOAT
+        return FMT_RGBA8_UNORM_SRGB if self.srgb else FMT_RGBA8_UNORM
+
+
+@dataclass
+class HeapItem:                  # one descriptor: a buffer (stride = typed element size) or a texture
+    array: np.ndarray
+    stride: int = 0
+    kind: int = KIND_BUFFER
+    width: int = 0
+    height: int = 0
+    fmt: int = 0
+
+
 @dataclass
 class Mesh:                      # Source/Model.ixx:26-47
     vertices: np.ndarray         # L.VERTEX
     indices: np.ndarray          # uint16 / uint32
     has_normals: bool = True
     material: np.ndarray = None  # L.MATERIAL scalar, None => Material() (App.cpp:1044)
+    has_tangents: bool = False
+    has_uv: tuple = (False, False)
+    textures: dict = None        # slot name (TEX_SLOTS) -> (Texture, TextureCoordinateIndex)
 
 
 @dataclass
@@ -80,7 +116,8 @@ class Scene:
     scene_data: np.ndarray = None
     name: str = "scene"
     # flattened, filled by finalize()
-    heap: list = field(default_factory=list)          # list of (np.ndarray bytes-owner, stride)
+    env_texture: Texture = None                       # EnvironmentLight.Texture (Scene.ixx:56-60): 2D lat-long or cube
+    heap: list = field(default_factory=list)          # list of HeapItem
     geometry: list = field(default_factory=list)      # per BLAS geometry: (mesh, heap_v, heap_i)
     blas: list = field(default_factory=list)          # (first_geometry, geometry_count) per node
     object_data: np.ndarray = None
@@ -92,17 +129,29 @@ class Scene:
     def finalize(self):
         """Scene::Refresh + App::UpdateScene: InstanceData / ObjectData / descriptor heap."""
         self.heap, self.geometry, self.blas = [], [], []
-        mesh_heap = {}
+        mesh_heap, tex_heap = {}, {}
+
+        def tex_descriptor(tex):
+            if id(tex) not in tex_heap:
+                cube = tex.data.ndim == 4 and tex.data.shape[0] == 6 and tex.data.shape[-1] == 4 and tex.data.shape[1] == tex.data.shape[2]
+                h, w = tex.data.shape[-3], tex.data.shape[-2]
+                tex_heap[id(tex)] = len(self.heap)
+                self.heap.append(HeapItem(np.ascontiguousarray(tex.data), 0, KIND_TEXTURECUBE if cube else KIND_TEXTURE2D, w, h, tex.fmt))
+            return tex_heap[id(tex)]
+
         for node in self.nodes:
             first = len(self.geometry)
             for mesh in node.meshes:
                 key = id(mesh)
                 if key not in mesh_heap:
-                    hv = len(self.heap); self.heap.append((mesh.vertices, 0))
-                    hi = len(self.heap); self.heap.append((mesh.indices, mesh.indices.dtype.itemsize))
+                    hv = len(self.heap); self.heap.append(HeapItem(mesh.vertices, 0))
+                    hi = len(self.heap); self.heap.append(HeapItem(mesh.indices, mesh.indices.dtype.itemsize))
                     mesh_heap[key] = (hv, hi)
                 self.geometry.append((mesh,) + mesh_heap[key])
             self.blas.append((first, len(node.meshes)))
+        if self.env_texture is not None and self.scene_data is not None:
+            self.scene_data["EnvironmentLightTextureDescriptor"] = tex_descriptor(self.env_texture)
+            self.scene_data["IsEnvironmentLightTextureCubeMap"] = 1 if self.heap[tex_heap[id(self.env_texture)]].kind == KIND_TEXTURECUBE else 0
         n_inst = len(self.objects)
         self.instance_data = np.zeros(n_inst, L.INSTANCE_DATA)
         self.instance_ids = np.zeros(n_inst, np.uint32)
@@ -124,13 +173,17 @@ class Scene:
                 od = np.zeros((), L.OBJECT_DATA)
                 od["VertexDesc"]["Stride"] = L.VERTEX.itemsize
                 od["VertexDesc"]["Normal"] = 12 if mesh.has_normals else L.NONE
-                od["VertexDesc"]["Tangent"] = L.NONE
-                od["VertexDesc"]["TexCoord"] = (L.NONE, L.NONE)
+                od["VertexDesc"]["Tangent"] = 18 if mesh.has_tangents else L.NONE
+                od["VertexDesc"]["TexCoord"] = (24 if mesh.has_uv[0] else L.NONE, 28 if mesh.has_uv[1] else L.NONE)
                 od["MeshDescriptors"]["Vertices"] = hv
                 od["MeshDescriptors"]["Indices"] = hi
                 od["MeshDescriptors"]["MotionVectors"] = L.NONE
                 od["Material"] = mesh.material if mesh.material is not None else L.default_material()
                 od["TextureMapInfoArray"]["Descriptor"] = L.NONE
+                for slot, (tex, uv_index) in (mesh.textures or {}).items():       # App.cpp:1052-1063
+                    k = TEX_SLOTS.index(slot)
+                    od["TextureMapInfoArray"][k]["Descriptor"] = tex_descriptor(tex)
+                    od["TextureMapInfoArray"][k]["TextureCoordinateIndex"] = uv_index
                 objs.append(od)
             object_index += count
         self.object_data = np.array(objs, L.OBJECT_DATA) if objs else np.zeros(0, L.OBJECT_DATA)
@@ -209,11 +262,18 @@ def material(base=(0.73, 0.73, 0.73), emissive=(0, 0, 0), strength=1.0, metallic
     return m
 
 
-def quad_mesh(p0, p1, p2, p3, normal, mat, has_normals=True):
-    """Two triangles (p0,p1,p2), (p0,p2,p3)."""
+def quad_mesh(p0, p1, p2, p3, normal, mat, has_normals=True, uv_scale=None, textures=None, uv1_scale=None):
+    """Two triangles (p0,p1,p2), (p0,p2,p3). uv_scale adds TexCoord0 = corner * scale and a tangent along p0->p1."""
     pos = np.array([p0, p1, p2, p3], np.float32)
     nrm = np.tile(np.asarray(normal, np.float32), (4, 1))
-    return Mesh(make_vertices(pos, nrm), make_indices([0, 1, 2, 0, 2, 3]), has_normals, mat)
+    if uv_scale is None:
+        return Mesh(make_vertices(pos, nrm), make_indices([0, 1, 2, 0, 2, 3]), has_normals, mat)
+    corners = np.array([(0, 0), (1, 0), (1, 1), (0, 1)], np.float32)
+    tan = pos[1] - pos[0]
+    tan = np.tile(tan / np.linalg.norm(tan), (4, 1))
+    uvs1 = corners * uv1_scale if uv1_scale is not None else None
+    return Mesh(make_vertices(pos, nrm, corners * uv_scale, tan, uvs1), make_indices([0, 1, 2, 0, 2, 3]), has_normals, mat,
+                has_tangents=True, has_uv=(True, uvs1 is not None), textures=textures)
 
 
 def box_mesh(mat, has_normals=True):
@@ -297,6 +357,81 @@ def cornell_box(aspect=16 / 9, variant="ggx", glass_sphere=False, has_normals=Tr
         objects.append(RenderObject(8, trs((0.35, -0.15, -0.25), 0.0, (0.25, 0.25, 0.25))))
     cam = make_camera((0, 0, -1.95), hfov_deg=90.0, aspect=aspect, jitter=jitter)
     return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, 1)), name="cornell_" + variant).finalize()
+
+
+def _checker(n, cells, c0, c1, alpha0=255, alpha1=255):
+    y, x = np.mgrid[0:n, 0:n]
+    m = (((x * cells) // n + (y * cells) // n) % 2).astype(bool)
+    img = np.zeros((n, n, 4), np.uint8)
+    img[~m] = tuple(c0) + (alpha0,)
+    img[m] = tuple(c1) + (alpha1,)
+    return img
+
+
+def cornell_box_textured(aspect=16 / 9, env="latlong", seed=7):
+    """Cornell box exercising every texture slot of Material.ixx:22-33 plus alpha-tested geometry and an
+    environment texture: checker base colour (sRGB) + normal map + packed metallic-roughness on the floor,
+    separate metallic / roughness maps on the back wall, emissive texture on a panel, transmission texture on a pane,
+    an alpha-masked (AlphaMode Mask) lattice in front of the light, lat-long or cube HDR environment."""
+    rng = np.random.default_rng(seed)
+    white, red, green = (0.73, 0.73, 0.73), (0.65, 0.05, 0.05), (0.12, 0.45, 0.15)
+    n = 32
+    base = Texture(_checker(n, 8, (230, 230, 230), (120, 60, 30)), srgb=True)
+    nm = np.zeros((n, n, 4), np.uint8)
+    ang = rng.random((n, n)) * 2 * np.pi; tilt = rng.random((n, n)) * 0.35
+    nm[..., 0] = np.clip((np.cos(ang) * tilt * 0.5 + 0.5) * 255, 0, 255)
+    nm[..., 1] = np.clip((np.sin(ang) * tilt * 0.5 + 0.5) * 255, 0, 255)
+    nm[..., 2] = 255; nm[..., 3] = 255
+    normal_map = Texture(nm)
+    mr = np.zeros((n, n, 4), np.uint8)
+    mr[..., 1] = rng.integers(40, 255, (n, n)); mr[..., 2] = (rng.random((n, n)) > 0.7) * 255; mr[..., 3] = 255
+    metal_rough = Texture(mr)
+    single = Texture(np.repeat(rng.integers(30, 255, (n, n, 1)), 4, -1).astype(np.uint8))
+    single2 = Texture(np.repeat(rng.integers(0, 255, (n, n, 1)), 4, -1).astype(np.uint8))
+    emis = Texture(_checker(n, 4, (255, 180, 60), (20, 20, 80)), srgb=True)
+    lattice = Texture(_checker(n, 6, (200, 200, 40), (10, 10, 10), alpha0=255, alpha1=0), srgb=True)
+    trans = Texture(_checker(n, 2, (255, 255, 255), (60, 60, 60)))
+    fl = material(white, metallic=1.0, roughness=1.0)
+    bw = material(white, metallic=0.8, roughness=0.9)
+    panel = material((0.2, 0.2, 0.2), emissive=(1, 1, 1), strength=4.0)
+    mask = material((1, 1, 1)); mask["AlphaMode"] = 1; mask["AlphaCutoff"] = 0.5
+    pane = material((0.95, 0.98, 1.0), roughness=0.08, transmission=1.0)
+    nodes = [
+        MeshNode([quad_mesh((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1), (0, 1, 0), fl, uv_scale=3.0, uv1_scale=1.0,
+                            textures={"BaseColor": (base, 0), "Normal": (normal_map, 0), "MetallicRoughness": (metal_rough, 1)})]),
+        MeshNode([quad_mesh((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1), (0, -1, 0), material(white))]),
+        MeshNode([quad_mesh((-1, -1, 1), (-1, 1, 1), (1, 1, 1), (1, -1, 1), (0, 0, -1), bw, uv_scale=2.0,
+                            textures={"Metallic": (single, 0), "Roughness": (single2, 0), "BaseColor": (base, 0)})]),
+        MeshNode([quad_mesh((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1), (1, 0, 0), material(red))]),
+        MeshNode([quad_mesh((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1), (-1, 0, 0), material(green))]),
+        MeshNode([quad_mesh((-0.25, 0, -0.25), (0.25, 0, -0.25), (0.25, 0, 0.25), (-0.25, 0, 0.25), (0, -1, 0),
+                            material((0.78, 0.78, 0.78), emissive=(1, 1, 1), strength=15.0))]),
+        MeshNode([quad_mesh((-0.5, -0.5, 0), (0.5, -0.5, 0), (0.5, 0.5, 0), (-0.5, 0.5, 0), (0, 0, -1), panel, uv_scale=1.0,
+                            textures={"EmissiveColor": (emis, 0)})]),
+        MeshNode([quad_mesh((-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), (0, -1, 0), mask, uv_scale=1.0,
+                            textures={"BaseColor": (lattice, 0)})]),
+        MeshNode([quad_mesh((-0.5, -0.5, 0), (0.5, -0.5, 0), (0.5, 0.5, 0), (-0.5, 0.5, 0), (0, 0, -1), pane, uv_scale=1.0,
+                            textures={"Transmission": (trans, 0)})]),
+    ]
+    ident = trs()
+    objects = [RenderObject(i, ident) for i in range(5)]
+    objects.append(RenderObject(5, trs((0, 0.998, 0.1))))
+    objects.append(RenderObject(6, trs((-0.4, -0.2, 0.95), 0.0, (0.8, 0.8, 1))))
+    objects.append(RenderObject(7, trs((0, 0.6, 0.1), 0.0, (1.2, 1, 1.2))))
+    objects.append(RenderObject(8, trs((0.45, -0.45, -0.2), 25.0, (0.9, 1.0, 1))))
+    sc = Scene(nodes, objects, make_camera((0, 0, -1.95), hfov_deg=90.0, aspect=aspect), make_scene_data((0, 0, 0, 1)),
+               name="cornell_textured_" + str(env))
+    if env == "latlong":
+        h, w = 16, 32
+        e = np.zeros((h, w, 4), np.float32)
+        e[..., :3] = (0.2 + rng.random((h, w, 3)) * 0.6) * np.linspace(2.0, 0.2, h)[:, None, None]
+        e[2, 5, :3] = 40.0                                      # a small "sun"
+        sc.env_texture = Texture(e)
+    elif env == "cube":
+        e = (0.1 + rng.random((6, 8, 8, 4)) * 0.9).astype(np.float32)
+        e[2] *= 3.0
+        sc.env_texture = Texture(e)
+    return sc.finalize()
 
 
 def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24):

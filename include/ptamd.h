@@ -166,6 +166,17 @@ int  pt_sync(PtContext* ctx);                               /* reference: Comman
  * ------------------------------------------------------------------------------------------ */
 int  pt_heap_resize(PtContext* ctx, uint32_t descriptor_count);
 int  pt_heap_set_buffer(PtContext* ctx, uint32_t descriptor, const void* device_ptr, uint64_t bytes, uint32_t stride);
+/* Texture2D / TextureCube SRV (reference: Texture::GetSRVDescriptor, indices stored in TextureMapInfo.Descriptor
+ * at Source/App.cpp:1052-1063 and in SceneData.EnvironmentLightTextureDescriptor at :1021-1024). Mip 0 only: the
+ * path samples with SampleLevel(sampler, uv, 0) (Shaders/ShadingHelpers.hlsli:58). Linear row-major texels;
+ * a cube is 6 faces +X,-X,+Y,-Y,+Z,-Z back to back. */
+typedef enum PtFormat {
+    PT_FORMAT_R8G8B8A8_UNORM = 0,
+    PT_FORMAT_R8G8B8A8_UNORM_SRGB = 1,     /* base colour / emissive textures (Source/GLTFHelpers.ixx:375-391) */
+    PT_FORMAT_R32G32B32A32_FLOAT = 2       /* HDR environment maps */
+} PtFormat;
+int  pt_heap_set_texture(PtContext* ctx, uint32_t descriptor, const void* device_ptr, uint32_t width, uint32_t height,
+                         uint32_t format, uint32_t is_cube);
 
 /* ------------------------------------------------------------------------------------------
  * acceleration structures

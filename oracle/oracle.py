@@ -37,7 +37,7 @@ class InstanceDesc(C.Structure):
 
 
 class HeapEntry(C.Structure):
-    _fields_ = [("Ptr", C.c_void_p), ("Bytes", C.c_uint64), ("Stride", C.c_uint32), ("_pad", C.c_uint32)]
+    _fields_ = [("Ptr", C.c_void_p), ("Bytes", C.c_uint64), ("Stride", C.c_uint32), ("Kind", C.c_uint32)]
 
 
 GB_NAMES = ["Position", "FlatNormal", "GeometricNormal", "LinearDepth", "NormalizedDepth", "MotionVector",
@@ -79,6 +79,8 @@ def lib():
         L.or_env_term_rtg.argtypes = [fp, C.c_float, C.c_float, fp]
         L.or_safe_spawn.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp]
         L.or_invert_3x4.argtypes = [fp, fp]
+        L.or_texture_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
+        L.or_cube_sample.argtypes = [C.c_void_p, fp, fp]
         _LIB = L
     return _LIB
 
@@ -104,7 +106,8 @@ class OracleScene:
             g.VertexCount, g.VertexStride = len(mesh.vertices), mesh.vertices.dtype.itemsize
             g.Indices = mesh.indices.ctypes.data
             g.IndexCount, g.IndexStride = mesh.indices.size, mesh.indices.dtype.itemsize
-            g.Flags = 1
+            alpha_mode = int(mesh.material["AlphaMode"]) if mesh.material is not None else 0
+            g.Flags = 1 if alpha_mode == 0 else 0       # OPAQUE iff AlphaMode::Opaque or no material (Scene.ixx:320-324)
         self._blas = (BlasDesc * max(1, len(scene.blas)))()
         for i, (f, c) in enumerate(scene.blas):
             self._blas[i].FirstGeometry, self._blas[i].GeometryCount = f, c
@@ -117,8 +120,13 @@ class OracleScene:
             self._inst[i].InstanceMask = int(scene.instance_masks[i])
             self._inst[i].Blas = int(scene.instance_blas[i])
         self._heap = (HeapEntry * max(1, len(scene.heap)))()
-        for i, (arr, stride) in enumerate(scene.heap):
-            self._heap[i].Ptr, self._heap[i].Bytes, self._heap[i].Stride = arr.ctypes.data, arr.nbytes, stride
+        for i, item in enumerate(scene.heap):
+            e = self._heap[i]
+            e.Ptr, e.Kind = item.array.ctypes.data, item.kind
+            if item.kind == 0:
+                e.Bytes, e.Stride = item.array.nbytes, item.stride
+            else:                                                   # texture: Bytes = width | height << 32, Stride = format
+                e.Bytes, e.Stride = item.width | (item.height << 32), item.fmt
         self._od = np.ascontiguousarray(scene.object_data)
         self._id = np.ascontiguousarray(scene.instance_data)
         self.handle = L.or_scene_create(C.addressof(self._geoms), len(scene.geometry), C.addressof(self._blas), len(scene.blas),

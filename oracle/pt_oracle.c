@@ -576,8 +576,9 @@ void or_safe_spawn(const float v[9], const float bary[2], const float M[12], con
 
 typedef struct {                 /* Shaders/HitInfo.hlsli:7-22 (texture coordinates/tangent: untextured scope) */
     f3 Position, ObjectPosition; float PositionOffset;
-    f3 FlatNormal, GeometricNormal, ShadingNormal;
+    f3 FlatNormal, GeometricNormal, ShadingNormal, Tangent;
     int IsFrontFace;
+    float TextureCoordinates[2][2];
     float Bary[2];
     float Distance;
     uint32_t InstanceIndex, ObjectIndex, PrimitiveIndex;
@@ -592,10 +593,169 @@ static f3 safe_world_ray_origin(const HitInfo* h, f3 dir)
     return F3(fmaf(o, n.x, h->Position.x), fmaf(o, n.y, h->Position.y), fmaf(o, n.z, h->Position.z));
 }
 
+
+/* ======================================================================== */
+/* textures (ShadingHelpers.hlsli:53-59 Sample<T>: SampleLevel(g_anisotropicSampler, uv, 0))                 */
+/* The root-signature static sampler (Raytracing.hlsl:79 "StaticSampler(s0)") has D3D12's defaults: WRAP      */
+/* addressing, and at an explicit LOD the anisotropic filter degenerates to a bilinear tap of mip 0.          */
+/* [spec] weights in fp32 (hardware uses 8-bit fixed-point fractions), sRGB decoded per texel before the      */
+/* filter through a 256-entry table evaluated in double precision.                                            */
+/* ======================================================================== */
+static float g_srgb_lut[256];
+static int g_srgb_ready = 0;
+static void srgb_init(void)
+{
+    if (g_srgb_ready) return;
+    for (int i = 0; i < 256; i++) {
+        double c = i / 255.0;
+        g_srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
+    g_srgb_ready = 1;
+}
+
+static void texel_fetch(const OrHeapEntry* t, uint32_t face, uint32_t x, uint32_t y, float out[4])
+{
+    const uint32_t W = (uint32_t)(t->Bytes & 0xFFFFFFFFu), H = (uint32_t)(t->Bytes >> 32);
+    const size_t idx = ((size_t)face * H + y) * W + x;
+    if (t->Stride == OR_FMT_RGBA32_FLOAT) { memcpy(out, (const float*)t->Ptr + 4 * idx, 16); return; }
+    const uint8_t* p = (const uint8_t*)t->Ptr + 4 * idx;
+    if (t->Stride == OR_FMT_RGBA8_UNORM_SRGB) {
+        srgb_init();
+        out[0] = g_srgb_lut[p[0]]; out[1] = g_srgb_lut[p[1]]; out[2] = g_srgb_lut[p[2]];
+    } else { out[0] = unorm8_to_f32(p[0]); out[1] = unorm8_to_f32(p[1]); out[2] = unorm8_to_f32(p[2]); }
+    out[3] = unorm8_to_f32(p[3]);
+}
+
+static void bilinear(const OrHeapEntry* t, uint32_t face, float fx, float fy, int wrap, float out[4])
+{
+    const int W = (int)(t->Bytes & 0xFFFFFFFFu), H = (int)(t->Bytes >> 32);
+    float x0f = floorf(fx), y0f = floorf(fy);
+    float wx = fx - x0f, wy = fy - y0f;
+    int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    if (wrap) {
+        x0 = ((x0 % W) + W) % W; x1 = ((x1 % W) + W) % W; y0 = ((y0 % H) + H) % H; y1 = ((y1 % H) + H) % H;
+    } else {
+        x0 = x0 < 0 ? 0 : (x0 >= W ? W - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= W ? W - 1 : x1);
+        y0 = y0 < 0 ? 0 : (y0 >= H ? H - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= H ? H - 1 : y1);
+    }
+    float c00[4], c10[4], c01[4], c11[4];
+    texel_fetch(t, face, (uint32_t)x0, (uint32_t)y0, c00); texel_fetch(t, face, (uint32_t)x1, (uint32_t)y0, c10);
+    texel_fetch(t, face, (uint32_t)x0, (uint32_t)y1, c01); texel_fetch(t, face, (uint32_t)x1, (uint32_t)y1, c11);
+    for (int c = 0; c < 4; c++) {
+        float top = c00[c] * (1.0f - wx) + c10[c] * wx;
+        float bot = c01[c] * (1.0f - wx) + c11[c] * wx;
+        out[c] = top * (1.0f - wy) + bot * wy;
+    }
+}
+
+void or_texture_sample(const OrHeapEntry* t, float u, float v, float out[4])
+{
+    const float W = (float)(uint32_t)(t->Bytes & 0xFFFFFFFFu), H = (float)(uint32_t)(t->Bytes >> 32);
+    if (!(u == u) || !isfinite(u)) u = 0.0f;
+    if (!(v == v) || !isfinite(v)) v = 0.0f;
+    u = u - floorf(u); v = v - floorf(v);                    /* WRAP */
+    bilinear(t, 0, u * W - 0.5f, v * H - 0.5f, 1, out);
+}
+
+/* TextureCube.SampleLevel: D3D face selection (major axis), bilinear inside the face, clamped at its border */
+void or_cube_sample(const OrHeapEntry* t, const float d[3], float out[4])
+{
+    const float W = (float)(uint32_t)(t->Bytes & 0xFFFFFFFFu), H = (float)(uint32_t)(t->Bytes >> 32);
+    float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]), sc, tc, ma; uint32_t face;
+    if (ax >= ay && ax >= az) { ma = ax; if (d[0] >= 0.0f) { face = 0; sc = -d[2]; tc = -d[1]; } else { face = 1; sc = d[2]; tc = -d[1]; } }
+    else if (ay >= az) { ma = ay; if (d[1] >= 0.0f) { face = 2; sc = d[0]; tc = d[2]; } else { face = 3; sc = d[0]; tc = -d[2]; } }
+    else { ma = az; if (d[2] >= 0.0f) { face = 4; sc = d[0]; tc = -d[1]; } else { face = 5; sc = -d[0]; tc = -d[1]; } }
+    float u = (sc / ma + 1.0f) * 0.5f, v = (tc / ma + 1.0f) * 0.5f;
+    bilinear(t, face, u * W - 0.5f, v * H - 0.5f, 0, out);
+}
+
+/* Sample<T>(TextureMapInfo, textureCoordinates) ShadingHelpers.hlsli:53-59 */
+static void sample_map(const OrHeapEntry* heap, const OrTextureMapInfo* info, const float uv[2][2], float out[4])
+{
+    const float* c = uv[info->TextureCoordinateIndex & 1u];
+    or_texture_sample(&heap[info->Descriptor], c[0], c[1], out);
+}
+
+enum { TEX_BaseColor = 0, TEX_EmissiveColor, TEX_Metallic, TEX_Roughness, TEX_MetallicRoughness, TEX_Transmission, TEX_Normal };
+
+/* EvaluateBaseColor ShadingHelpers.hlsli:61-73 */
+static void evaluate_base_color(float bc[4], const OrHeapEntry* heap, const OrTextureMapInfo* info, const float uv[2][2])
+{
+    if ((bc[0] > 0.0f || bc[1] > 0.0f || bc[2] > 0.0f || bc[3] > 0.0f) && info->Descriptor != ~0u) {
+        float t[4]; sample_map(heap, info, uv, t);
+        for (int c = 0; c < 4; c++) bc[c] *= t[c];
+    }
+}
+
+/* IsOpaque ShadingHelpers.hlsli:105-115 (the closest-hit overload) */
+static int is_opaque(const OrObjectData* od, const OrHeapEntry* heap, const float uv[2][2])
+{
+    float bc[4]; memcpy(bc, od->Material.BaseColor, 16);
+    evaluate_base_color(bc, heap, &od->TextureMapInfoArray[TEX_BaseColor], uv);
+    return bc[3] >= od->Material.AlphaCutoff;
+}
+
+/* EvaluateMaterial ShadingHelpers.hlsli:161-235; N is the (front-facing) shading normal, T the front tangent */
+static OrMaterial evaluate_material(f3* N, f3 T, const OrObjectData* od, const OrHeapEntry* heap, const float uv[2][2])
+{
+    OrMaterial m = od->Material;
+    const OrTextureMapInfo* ti = od->TextureMapInfoArray;
+    float t[4];
+    evaluate_base_color(m.BaseColor, heap, &ti[TEX_BaseColor], uv);
+    f3 em = scl3(ld3(m.EmissiveColor), m.EmissiveStrength);
+    if ((em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) && ti[TEX_EmissiveColor].Descriptor != ~0u) {
+        sample_map(heap, &ti[TEX_EmissiveColor], uv, t);
+        m.EmissiveColor[0] *= t[0]; m.EmissiveColor[1] *= t[1]; m.EmissiveColor[2] *= t[2];
+    }
+    if (ti[TEX_MetallicRoughness].Descriptor != ~0u) {
+        if (m.Metallic > 0.0f || m.Roughness > 0.0f) {
+            sample_map(heap, &ti[TEX_MetallicRoughness], uv, t);
+            m.Metallic *= t[2]; m.Roughness *= t[1];
+        }
+    } else {
+        if (m.Metallic > 0.0f && ti[TEX_Metallic].Descriptor != ~0u) { sample_map(heap, &ti[TEX_Metallic], uv, t); m.Metallic *= t[0]; }
+        if (m.Roughness > 0.0f && ti[TEX_Roughness].Descriptor != ~0u) { sample_map(heap, &ti[TEX_Roughness], uv, t); m.Roughness *= t[0]; }
+    }
+    if (m.Metallic < 1.0f) {
+        if (m.Transmission > 0.0f && ti[TEX_Transmission].Descriptor != ~0u) { sample_map(heap, &ti[TEX_Transmission], uv, t); m.Transmission *= t[0]; }
+    }
+    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && ti[TEX_Normal].Descriptor != ~0u) {        /* PerturbNormal :89-103 */
+        sample_map(heap, &ti[TEX_Normal], uv, t);
+        /* [MathLib spec] Geometry::UnpackLocalNormal: xy*2-1, z = sqrt(saturate(1 - |xy|^2)) */
+        float nx = t[0] * 2.0f - 1.0f, ny = t[1] * 2.0f - 1.0f;
+        float nz = ml_sqrt01(1.0f - (nx * nx + ny * ny));
+        /* Math::CalculateTBN Math.hlsli:17-21 */
+        f3 Tn = normalize3(sub3(T, scl3(*N, dot3(*N, T))));
+        f3 B = cross3(*N, Tn);
+        f3 r = F3(Tn.x * nx + B.x * ny + N->x * nz, Tn.y * nx + B.y * ny + N->y * nz, Tn.z * nx + B.z * ny + N->z * nz);
+        *N = normalize3(r);
+    }
+    return m;
+}
+
+/* GetTextureCoordinates ShadingHelpers.hlsli:32-51 */
+static void get_texture_coordinates(const OrObjectData* od, const OrHeapEntry* heap, uint32_t prim, float bu, float bv, float uv[2][2])
+{
+    const OrHeapEntry* vb = &heap[od->MeshDescriptors.Vertices];
+    const OrHeapEntry* ib = &heap[od->MeshDescriptors.Indices];
+    for (int i = 0; i < 2; i++) {
+        uv[i][0] = uv[i][1] = 0.0f;
+        uint32_t off = od->VertexDesc.TextureCoordinates[i];
+        if (off == ~0u) continue;
+        float a[3][2];
+        for (int k = 0; k < 3; k++) {
+            uint32_t idx = ib->Stride == 2 ? (uint32_t)((const uint16_t*)ib->Ptr)[3 * prim + k] : ((const uint32_t*)ib->Ptr)[3 * prim + k];
+            uint16_t h[2]; memcpy(h, (const uint8_t*)vb->Ptr + (size_t)od->VertexDesc.Stride * idx + off, 4);
+            a[k][0] = or_f16_to_f32(h[0]); a[k][1] = or_f16_to_f32(h[1]);
+        }
+        for (int c = 0; c < 2; c++) uv[i][c] = a[0][c] + bu * (a[1][c] - a[0][c]) + bv * (a[2][c] - a[0][c]);
+    }
+}
+
 /* ======================================================================== */
 /* scene + traversal                                                         */
 /* ======================================================================== */
-typedef struct { f3 v0, v1, v2; uint32_t geom, prim; } Tri;           /* geom = GeometryIndex within the BLAS */
+typedef struct { f3 v0, v1, v2; uint32_t geom, prim, opaque; } Tri;           /* geom = GeometryIndex within the BLAS */
 typedef struct { float lo[3], hi[3]; uint32_t left, right, first, count; } Node; /* count>0 => leaf */
 
 typedef struct {
@@ -697,7 +857,11 @@ typedef struct {
 
 /* closest hit; ties on t resolved by (instance, geometry, primitive) lexicographic order so
  * the result does not depend on traversal order (DXR leaves ties undefined). */
-static inline void commit_candidate(Committed* c, float tmin, float t, float u, float v,
+static int is_opaque(const OrObjectData* od, const OrHeapEntry* heap, const float uv[2][2]);
+static void get_texture_coordinates(const OrObjectData* od, const OrHeapEntry* heap, uint32_t prim, float bu, float bv, float uv[2][2]);
+static int candidate_is_opaque(const OrScene* s, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
+
+static inline void commit_candidate(const OrScene* s, int opaque, Committed* c, float tmin, float t, float u, float v,
                                     uint32_t inst, uint32_t geom, uint32_t prim)
 {
     if (!(t > tmin)) return;
@@ -706,6 +870,8 @@ static inline void commit_candidate(Committed* c, float tmin, float t, float u, 
     else if (t == c->t && c->hit) {
         better = inst < c->inst || (inst == c->inst && (geom < c->geom || (geom == c->geom && prim < c->prim)));
     } else better = 0;
+    /* CANDIDATE_NON_OPAQUE_TRIANGLE: alpha test before the commit (RaytracingHelpers.hlsli:19-44) */
+    if (better && !opaque && !candidate_is_opaque(s, inst, geom, prim, u, v)) better = 0;
     if (better) { c->t = t; c->u = u; c->v = v; c->inst = inst; c->geom = geom; c->prim = prim; c->hit = 1; }
 }
 
@@ -722,14 +888,14 @@ static inline int box_test(const float lo[3], const float hi[3], f3 o, f3 inv, f
     return tn <= tf * 1.0000004f;
 }
 
-static void blas_intersect(const Blas* b, int accel, f3 o, f3 d, float tmin, uint32_t inst, Committed* c)
+static void blas_intersect(const OrScene* s, const Blas* b, int accel, f3 o, f3 d, float tmin, uint32_t inst, Committed* c)
 {
     RayObj r; ray_setup(&r, o, d);
     if (!accel) {
         for (uint32_t i = 0; i < b->n_tris; i++) {
             float t, u, v;
             if (tri_test(&r, b->tris[i].v0, b->tris[i].v1, b->tris[i].v2, &t, &u, &v))
-                commit_candidate(c, tmin, t, u, v, inst, b->tris[i].geom, b->tris[i].prim);
+                commit_candidate(s, (int)b->tris[i].opaque, c, tmin, t, u, v, inst, b->tris[i].geom, b->tris[i].prim);
         }
         return;
     }
@@ -743,7 +909,7 @@ static void blas_intersect(const Blas* b, int accel, f3 o, f3 d, float tmin, uin
             for (uint32_t i = n->first; i < n->first + n->count; i++) {
                 float t, u, v;
                 if (tri_test(&r, b->tris[i].v0, b->tris[i].v1, b->tris[i].v2, &t, &u, &v))
-                    commit_candidate(c, tmin, t, u, v, inst, b->tris[i].geom, b->tris[i].prim);
+                    commit_candidate(s, (int)b->tris[i].opaque, c, tmin, t, u, v, inst, b->tris[i].geom, b->tris[i].prim);
             }
         } else { stack[sp++] = n->left; stack[sp++] = n->right; }
     }
@@ -760,7 +926,7 @@ static inline void instance_intersect(const OrScene* s, uint32_t ii, f3 o, f3 d,
     f3 od = F3(W[0] * d.x + W[1] * d.y + W[2]  * d.z,
                W[4] * d.x + W[5] * d.y + W[6]  * d.z,
                W[8] * d.x + W[9] * d.y + W[10] * d.z);
-    blas_intersect(&s->blas[in->Blas], s->accel_mode, oo, od, tmin, ii, c);
+    blas_intersect(s, &s->blas[in->Blas], s->accel_mode, oo, od, tmin, ii, c);
 }
 
 /* TraceRay (RaytracingHelpers.hlsli:7-55) with flags NONE, mask ~0: closest hit, no culling,
@@ -861,7 +1027,7 @@ OrScene* or_scene_create(const OrGeometryDesc* geoms, uint32_t n_geoms,
                     uint32_t idx = load_index(G->Indices, G->IndexStride, 3 * p + c);
                     pv[c] = (const float*)((const uint8_t*)G->Vertices + (size_t)G->VertexStride * idx);
                 }
-                T->v0 = ld3(pv[0]); T->v1 = ld3(pv[1]); T->v2 = ld3(pv[2]); T->geom = g; T->prim = p;
+                T->v0 = ld3(pv[0]); T->v1 = ld3(pv[1]); T->v2 = ld3(pv[2]); T->geom = g; T->prim = p; T->opaque = G->Flags & 1u;
                 for (int c = 0; c < 3; c++) for (int a = 0; a < 3; a++) {
                     B->lo[a] = fminf(B->lo[a], pv[c][a]); B->hi[a] = fmaxf(B->hi[a], pv[c][a]);
                 }
@@ -931,6 +1097,14 @@ void or_scene_destroy(OrScene* s)
     free(s->objects); free(s->inst_data); free(s->heap); free(s);
 }
 
+static int candidate_is_opaque(const OrScene* s, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
+{
+    const OrObjectData* od = &s->objects[s->inst[inst].InstanceID + geom];
+    float uv[2][2];
+    get_texture_coordinates(od, s->heap, prim, u, v, uv);
+    return is_opaque(od, s->heap, uv);
+}
+
 /* ======================================================================== */
 /* CastRay (RaytracingHelpers.hlsli:57-133)                                  */
 /* ======================================================================== */
@@ -980,12 +1154,37 @@ static int cast_ray(const OrScene* s, const RayDesc* ray, HitInfo* h)
     h->ShadingNormal = h->GeometricNormal;
     h->IsFrontFace = dot3(h->GeometricNormal, ray->Direction) < 0.0f;
     if (!h->IsFrontFace) h->ShadingNormal = neg3(h->ShadingNormal);
+    h->Tangent = F3(0, 0, 0);                            /* :115-122 */
+    if (od->VertexDesc.Tangent != ~0u) {
+        f3 tg[3];
+        for (int k = 0; k < 3; k++) {
+            int16_t q[3]; memcpy(q, vbase + (size_t)stride * idx[k] + od->VertexDesc.Tangent, 6);
+            tg[k] = F3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
+        }
+        f3 t = add3(add3(tg[0], scl3(sub3(tg[1], tg[0]), c.u)), scl3(sub3(tg[2], tg[0]), c.v));
+        const float* M = in->Transform;
+        f3 w = F3(M[0] * t.x + M[1] * t.y + M[2] * t.z, M[4] * t.x + M[5] * t.y + M[6] * t.z, M[8] * t.x + M[9] * t.y + M[10] * t.z);
+        h->Tangent = normalize3(w);
+    }
+    get_texture_coordinates(od, s->heap, c.prim, c.u, c.v, h->TextureCoordinates);       /* :124-130 */
     return 1;
 }
 
 /* ShadingHelpers.hlsli:11-30 (no environment texture: SURVEY 8f "next") */
-static f3 environment_light_color(const OrSceneData* sd, f3 dir)
+static f3 environment_light_color(const OrScene* s, const OrSceneData* sd, f3 dir)
 {
+    if (sd->EnvironmentLightTextureDescriptor != ~0u) {
+        const float* M = sd->EnvironmentLightTransform;
+        f3 w = normalize3(F3(M[0] * dir.x + M[1] * dir.y + M[2] * dir.z, M[4] * dir.x + M[5] * dir.y + M[6] * dir.z, M[8] * dir.x + M[9] * dir.y + M[10] * dir.z));
+        const OrHeapEntry* t = &s->heap[sd->EnvironmentLightTextureDescriptor];
+        float out[4];
+        if (sd->IsEnvironmentLightTextureCubeMap) { float d[3] = { w.x, w.y, w.z }; or_cube_sample(t, d, out); }
+        else {                                              /* Math::ToLatLongCoordinate Math.hlsli:29-33 */
+            const float Pi = 3.14159265358979323846f;
+            or_texture_sample(t, (1.0f + atan2f(w.x, w.z) / Pi) / 2.0f, acosf(w.y) / Pi, out);
+        }
+        return F3(out[0], out[1], out[2]);
+    }
     if (sd->EnvironmentLightColor[3] >= 0.0f) return ld3(sd->EnvironmentLightColor);
     float t = (dir.y + 1.0f) * 0.5f;
     return F3(ml_from_srgb1(1.0f + t * (0.5f - 1.0f)), ml_from_srgb1(1.0f + t * (0.7f - 1.0f)), ml_from_srgb1(1.0f + t * (1.0f - 1.0f)));
@@ -1074,7 +1273,9 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
                 }
                 BSDFSample bs; memset(&bs, 0, sizeof bs);
                 if (flags & OR_GB_Material) {
-                    const OrMaterial* m = &s->objects[h.ObjectIndex].Material;   /* EvaluateMaterial, untextured */
+                    f3 frontT = h.IsFrontFace ? h.Tangent : neg3(h.Tangent);             /* GetFrontTangent */
+                    const OrMaterial mm = evaluate_material(&h.ShadingNormal, frontT, &s->objects[h.ObjectIndex], s->heap, h.TextureCoordinates);
+                    const OrMaterial* m = &mm;
                     bsdf_init(&bs, ld3(m->BaseColor), m->Metallic, m->Roughness, m->IOR, m->Transmission, h.IsFrontFace);
                     if (tx->BaseColorMetalness) {
                         tx->BaseColorMetalness[4 * pi + 0] = or_f32_to_unorm8(bs.BaseColor.x);
@@ -1109,7 +1310,7 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
                     tx->MotionVector[4 * pi + 3] = 0;
                 }
                 if ((flags & OR_GB_Radiance) && tx->Radiance) {
-                    f3 e = environment_light_color(sd, ray.Direction);
+                    f3 e = environment_light_color(s, sd, ray.Direction);
                     tx->Radiance[4 * pi + 0] = or_f32_to_f16(e.x); tx->Radiance[4 * pi + 1] = or_f32_to_f16(e.y);
                     tx->Radiance[4 * pi + 2] = or_f32_to_f16(e.z); tx->Radiance[4 * pi + 3] = 0;
                 }
@@ -1186,12 +1387,14 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                         total_rays++;
                     }
                     if (!isHit) {                                                       /* :241-259 */
-                        f3 env = environment_light_color(sd, ray.Direction);
+                        f3 env = environment_light_color(s, sd, ray.Direction);
                         sampleRadiance = add3(sampleRadiance, mul3(throughput, env));
                         break;
                     }
                     if (bounce) {                                                       /* :293-304 */
-                        const OrMaterial* m = &s->objects[hit.ObjectIndex].Material;
+                        f3 frontT = hit.IsFrontFace ? hit.Tangent : neg3(hit.Tangent);
+                        const OrMaterial mm = evaluate_material(&hit.ShadingNormal, frontT, &s->objects[hit.ObjectIndex], s->heap, hit.TextureCoordinates);
+                        const OrMaterial* m = &mm;
                         emission = material_emission(m);
                         bsdf_init(&bs, ld3(m->BaseColor), m->Metallic, m->Roughness, m->IOR, m->Transmission, hit.IsFrontFace);
                     }

@@ -155,9 +155,14 @@ typedef struct OrInstanceDesc {          /* D3D12_RAYTRACING_INSTANCE_DESC subse
     uint32_t _pad;
 } OrInstanceDesc;
 
-/* descriptor-heap analogue: ObjectData.MeshDescriptors.* index this table.
- * Stride: element size of a typed buffer (index buffers: 2 = R16_UINT, 4 = R32_UINT; raw vertex buffers: 0). */
-typedef struct OrHeapEntry { const void* Ptr; uint64_t Bytes; uint32_t Stride; uint32_t _pad; } OrHeapEntry;
+/* descriptor-heap analogue: ObjectData.MeshDescriptors.* / TextureMapInfo.Descriptor /
+ * SceneData.EnvironmentLightTextureDescriptor index this table.
+ * Kind 0 buffer : Stride = element size of a typed buffer (index buffers: 2 = R16_UINT, 4 = R32_UINT; raw: 0).
+ * Kind 1 Texture2D, Kind 2 TextureCube (faces +X,-X,+Y,-Y,+Z,-Z contiguous): Bytes = width | height << 32,
+ *        Stride = texel format (OR_FMT_*). Mip 0 only (the path samples with SampleLevel(..., 0)). */
+typedef struct OrHeapEntry { const void* Ptr; uint64_t Bytes; uint32_t Stride; uint32_t Kind; } OrHeapEntry;
+enum { OR_KIND_BUFFER = 0, OR_KIND_TEXTURE2D = 1, OR_KIND_TEXTURECUBE = 2 };
+enum { OR_FMT_RGBA8_UNORM = 0, OR_FMT_RGBA8_UNORM_SRGB = 1, OR_FMT_RGBA32_FLOAT = 2 };
 
 typedef struct OrScene OrScene;
 
@@ -206,6 +211,9 @@ void     or_env_term_rtg(const float f0[3], float NoV, float roughness, float ou
 void     or_safe_spawn(const float v[9], const float bary[2], const float o2w[12], const float w2o[12],
                        float objPos[3], float wldPos[3], float objN[3], float wldN[3], float* offset);
 void     or_invert_3x4(const float m[12], float out[12]);
+/* SampleLevel(sampler, uv, 0) of a heap texture: bilinear, wrap addressing, sRGB decode per texel */
+void     or_texture_sample(const OrHeapEntry* tex, float u, float v, float out[4]);
+void     or_cube_sample(const OrHeapEntry* tex, const float dir[3], float out[4]);
 
 #ifdef __cplusplus
 }

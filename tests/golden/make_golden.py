@@ -23,6 +23,8 @@ CASES = {
     "cornell_ggx_64x36_s2_b4": (lambda: S.cornell_box(aspect=64 / 36, variant="ggx", glass_sphere=True), 64, 36, 2, 4, 0),
     "cornell_lambert_64x64_s1_b2": (lambda: S.cornell_box(aspect=1.0, variant="diffuse", has_normals=False), 64, 64, 1, 2, 1),
     "cornell_ggx_jitter_48x27_s3_b8": (lambda: S.cornell_box(aspect=48 / 27, variant="ggx", jitter=(0.25, -0.375)), 48, 27, 3, 8, 0),
+    # every texture slot, normal map, alpha-masked geometry, constant environment (bit-pinned arithmetic: no libm call)
+    "cornell_textured_64x36_s2_b6": (lambda: S.cornell_box_textured(aspect=64 / 36, env=None), 64, 36, 2, 6, 0),
 }
 
 

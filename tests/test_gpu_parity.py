@@ -97,6 +97,38 @@ def test_cornell_bit_identical_to_oracle(case, gpu, ptamd, oracle, pkg):
     assert np.array_equal(out["Radiance"], ref_gb["Radiance"])             # the fp16 texture the reference consumer reads
 
 
+def test_textured_materials_alpha_test_and_environment_maps(gpu, ptamd, oracle, pkg):
+    """Rows a4/a5/a9/a10: UV + tangent interpolation, all seven texture slots, normal mapping, alpha-tested
+    (non-opaque) geometry inside traversal, cube and lat-long environment textures.
+    Constant environment and cube map: no libm on the path -> bit-identical. Lat-long goes through atan2f/acosf
+    (Math::ToLatLongCoordinate) -> tolerance."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 128, 72
+    for env in (None, "cube", "latlong"):
+        scene = S.cornell_box_textured(aspect=W / H, env=env)
+        gs = S.graphics_settings(W, H, spp=3, bounces=6, frame_index=2)
+        out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+        assert_gbuffer_identical(out, ref_gb)
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        st = ge.compare_radiance(out["RadianceF32"], ref_f32)
+        assert st["rms"] < L2_TOLERANCE
+        if env != "latlong":
+            assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32)), st
+            assert np.array_equal(out["Radiance"], ref_gb["Radiance"])
+        else:
+            assert st["max"] < 1e-3, st
+    # the alpha-masked lattice really is see-through where alpha < cutoff: primary rays aimed at it differ from an opaque copy
+    scene = S.cornell_box_textured(aspect=W / H, env=None)
+    scene.camera = S.make_camera((0, -0.6, 0.1), forward=(0, 1, 0.001), up=(0, 0, 1), hfov_deg=60.0, aspect=W / H)   # looking up through the lattice
+    gs = S.graphics_settings(W, H, spp=1, bounces=1)
+    out, _ = gpu_render(ptamd, gpu, scene, gs, W, H)
+    ref_gb, _, _ = oracle.render(scene, gs, accel_mode=0, layouts=L)
+    assert_gbuffer_identical(out, ref_gb)
+    ys = out["Position"][..., 1]
+    assert (np.abs(ys - 0.6) < 1e-3).any() and (ys > 0.9).any()       # some pixels stop at the lattice (y=0.6), others pass to the ceiling / light
+
+
 def test_bounces_zero_and_misses(gpu, ptamd, oracle, pkg):
     S, L = pkg.scenes, pkg.layouts
     W, H = 128, 32
