@@ -277,8 +277,15 @@ PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
     return base + prefix;
 }
 
-// enqueue every primary-hit pixel (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
-__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* counts)
+// Queue regions. Every sub-queue segment holds two kinds of entries, grown from its two ends:
+//   traced  [0, nT)                 paths whose ray has been traced by k_extend: state + ray + hit record
+//   fresh   (segCap-1 ... segCap-nF] paths about to start a sample at the primary surface: state only
+// k_shade consumes both kinds in two separate tile loops (no divergence between "reconstruct a hit" and "decode the
+// G-buffer"), and writes both kinds. A path that ends a sample with samples left re-enters as fresh, carrying its
+// RNG state (all samples of a pixel draw from one stream, Raytracing.hlsl:108,191).
+
+// enqueue every primary-hit pixel as fresh (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* countFresh)
 {
     __shared__ uint32_t lds[8];
     const uint32_t npix = fv.width * fv.localRows;
@@ -287,127 +294,165 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSetting
         const uint32_t p = (j * kSubQueues + sq) * 256u + threadIdx.x;
         bool alive = false;
         if (p < npix) alive = isfinite(((const float*)tx.Position)[4 * (size_t)p + 3]);
-        const uint32_t slot = sq * segCap + block_reserve(alive, &counts[sq], lds);
+        const uint32_t slot = sq * segCap + (segCap - 1u - block_reserve(alive, &countFresh[sq], lds));
         if (alive) {
             const uint32_t x = p % fv.width, y = global_row(fv, p / fv.width);
             q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
             q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng_init(x, y, gs.FrameIndex)));
-            q.s2[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(1u));            // sample 0, bounce 0, fresh
+            q.s2[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));            // sample 0, bounce 0
         }
     }
 }
 
+struct PathRegs { v3 thr, srad, rsum; uint32_t pixel, rng, sample, bounce; };
+
+PT_DEV PathRegs load_path(const PathQueue& q, uint32_t i)
+{
+    const float4 a = q.s0[i], b = q.s1[i], c = q.s2[i];
+    PathRegs p;
+    p.thr = V3(a.x, a.y, a.z); p.pixel = __float_as_uint(a.w);
+    p.srad = V3(b.x, b.y, b.z); p.rng = __float_as_uint(b.w);
+    p.rsum = V3(c.x, c.y, c.z);
+    const uint32_t cnt = __float_as_uint(c.w);
+    p.sample = cnt >> 16; p.bounce = cnt & 0xFFFFu;
+    return p;
+}
+PT_DEV void store_path(const PathQueue& q, uint32_t i, const PathRegs& p)
+{
+    q.s0[i] = make_float4(p.thr.x, p.thr.y, p.thr.z, __uint_as_float(p.pixel));
+    q.s1[i] = make_float4(p.srad.x, p.srad.y, p.srad.z, __uint_as_float(p.rng));
+    q.s2[i] = make_float4(p.rsum.x, p.rsum.y, p.rsum.z, __uint_as_float((p.sample << 16) | p.bounce));
+}
+
+// One iteration body of the bounce loop after the surface is known (Raytracing.hlsl:320-364): emission, lobe
+// weights, BSDF sample, throughput update, Russian roulette, luminance cut-off. Returns true when the path goes on
+// with the ray (newO, newD); false ends the sample. RNG draws happen exactly as in the reference, also on the last
+// iteration (bounce == Bounces), which samples but never traces (:213).
+PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit& h, const BSDFSample& bs, v3 emission, v3 rayDir, v3& newO, v3& newD)
+{
+    p.srad = p.srad + p.thr * emission;                          // :320
+    const SurfaceVectors svec = surface_vectors(h.IsFrontFace, h.GeometricNormal, h.ShadingNormal);
+    const v3 V = -rayDir;
+    float w[3]; bs.ComputeLobeWeights(svec, V, gs.ExtFlags, w);
+    float rnd[4];
+    rnd[0] = rng_float(p.rng); rnd[1] = rng_float(p.rng); rnd[2] = rng_float(p.rng); rnd[3] = rng_float(p.rng);   // GetFloat4, :330
+    v3 L; int lobe;
+    if (!bs.Sample(svec, V, w, rnd, L, lobe)) return false;
+    float pdf; v3 f;
+    bs.EvaluateLobe(svec, L, V, w, lobe, gs.ExtFlags, pdf, f);
+    if (pdf == 0.0f || (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f)) return false;             // :336,342
+    p.thr = p.thr * V3(f.x / pdf, f.y / pdf, f.z / pdf);                                      // :346
+    if (gs.IsRussianRouletteEnabled && p.bounce > 3) {                                        // :348-356
+        const float prob = fmaxf(p.thr.x, fmaxf(p.thr.y, p.thr.z));
+        if (rng_float(p.rng) >= prob) return false;
+        p.thr = V3(p.thr.x / prob, p.thr.y / prob, p.thr.z / prob);
+    }
+    if (ml_luminance(p.thr) <= gs.ThroughputThreshold) return false;                          // :361
+    if (!(p.bounce < gs.Bounces)) return false;                                               // loop bound, :213
+    newO = safe_world_ray_origin(h.Position, h.FlatNormal, h.PositionOffset, L);              // :221
+    newD = L;
+    p.bounce++;
+    return true;
+}
+
+// sample ended: accumulate, start the next sample of the pixel or finish the pixel (Raytracing.hlsl:372-386)
+PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, PathRegs& p)
+{
+    p.rsum = p.rsum + p.srad;                                    // :372
+    p.sample++;
+    if (p.sample < gs.SamplesPerPixel) { p.thr = V3(1, 1, 1); p.srad = V3(0, 0, 0); p.bounce = 0; return true; }
+    v3 out = V3(0, 0, 0);
+    if (finite3(p.rsum)) { const float ns = (float)gs.SamplesPerPixel; out = V3(p.rsum.x / ns, p.rsum.y / ns, p.rsum.z / ns); }
+    ((ushort4*)tx.Radiance)[p.pixel] = make_ushort4(f32_to_f16(out.x), f32_to_f16(out.y), f32_to_f16(out.z), 0);
+    if (tx.RadianceF32) ((float4*)tx.RadianceF32)[p.pixel] = make_float4(out.x, out.y, out.z, 0.0f);
+    return false;
+}
+
+// counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, PtGraphicsSettings gs, PtTextures tx,
                                                PathQueue qin, PathQueue qout, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
     __shared__ uint32_t lds[8];
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
-    const uint32_t n = countIn[sq];
-    for (uint32_t tile = bq; tile * 256u < n; tile += nbq) {
+    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
+    const uint32_t seg = sq * segCap;
+
+    // ---- traced paths: the hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304
+    for (uint32_t tile = bq; tile * 256u < nT; tile += nbq) {
         const uint32_t local = tile * 256u + threadIdx.x;
-        const uint32_t i = sq * segCap + local;
-        bool alive = false;
-        v3 thr = V3(1, 1, 1), srad = V3(0, 0, 0), rsum = V3(0, 0, 0), newO = V3(0, 0, 0), newD = V3(0, 0, 1);
-        uint32_t pixel = 0, rng = 0, sample = 0, bounce = 0;
-        if (local < n) {
-            const float4 a = qin.s0[i], b = qin.s1[i], c = qin.s2[i];
-            thr = V3(a.x, a.y, a.z); pixel = __float_as_uint(a.w);
-            srad = V3(b.x, b.y, b.z); rng = __float_as_uint(b.w);
-            rsum = V3(c.x, c.y, c.z);
-            const uint32_t cnt = __float_as_uint(c.w);
-            sample = cnt >> 16; bounce = (cnt >> 1) & 0x7FFFu;
-            bool pending = !(cnt & 1u);                                    // a traced ray's hit record is waiting
+        const uint32_t i = seg + local;
+        bool toTraced = false, toFresh = false;
+        PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        if (local < nT) {
+            p = load_path(qin, i);
+            const uint4 hr = qin.hit[i];
+            const float4 rd = qin.r1[i];
+            const v3 rayDir = V3(rd.x, rd.y, rd.z);
+            bool goes = false;
+            if (hr.x == ~0u) {                                   // :241-259
+                p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
+            } else {                                             // :293-304
+                SurfaceHit h;
+                reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+                const PtMaterial m = surface_material<TEXTURED>(sv, h);
+                BSDFSample bs;
+                bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
+                goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD);
+            }
+            if (goes) toTraced = true;
+            else toFresh = end_sample(gs, tx, p);
+        }
+        const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
+        const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
+        if (toTraced) {
+            store_path(qout, seg + st, p);
+            qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
+            qout.r1[seg + st] = make_float4(newD.x, newD.y, newD.z, INFINITY);                // TMax = inf, :224
+        }
+        if (toFresh) store_path(qout, seg + (segCap - 1u - sf), p);
+    }
+
+    // ---- fresh paths: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
+    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
+        const uint32_t local = tile * 256u + threadIdx.x;
+        bool toTraced = false, toFresh = false;
+        PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        if (local < nF) {
+            p = load_path(qin, seg + (segCap - 1u - local));
+            const uint32_t pixel = p.pixel;
             const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
             float uu, vv;
-            const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // Raytracing.hlsl:110-126
-
-            while (true) {
-                SurfaceHit h; BSDFSample bs; v3 emission = V3(0, 0, 0), rayDir; bool isHit = true;
-                if (pending) {                                             // bounce >= 1, Raytracing.hlsl:219-233 done by k_extend
-                    pending = false;
-                    const uint4 hr = qin.hit[i];
-                    const float4 rd = qin.r1[i];
-                    rayDir = V3(rd.x, rd.y, rd.z);
-                    if (hr.x == ~0u) {                                     // :241-259
-                        srad = srad + thr * environment_light_color(sv, sd, rayDir);
-                        isHit = false;
-                    } else {                                               // :293-304
-                        reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
-                        const PtMaterial m = surface_material<TEXTURED>(sv, h);
-                        emission = material_emission(m);
-                        bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
-                    }
-                } else {                                                   // bounce 0: primary surface from the G-buffer, :118-148
-                    bounce = 0;
-                    rayDir = primaryRay.d;
-                    const float4 pos = ((const float4*)tx.Position)[pixel];
-                    const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
-                    const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
-                    const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
-                    const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
-                    h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;      // HitInfo.hlsli:67-79
-                    h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
-                    h.GeometricNormal = oct_decode(snorm16_to_f32(ge.x), snorm16_to_f32(ge.y));
-                    h.ShadingNormal = V3(snorm16_to_f32(nr.x), snorm16_to_f32(nr.y), snorm16_to_f32(nr.z));
-                    h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
-                    emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));     // :119,197
-                    const float metal = unorm8_to_f32(bcm.w);
-                    const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
-                    const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
-                    bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
-                }
-                bool continues = false;
-                if (isHit) {
-                    srad = srad + thr * emission;                          // :320
-                    const SurfaceVectors svec = surface_vectors(h.IsFrontFace, h.GeometricNormal, h.ShadingNormal);
-                    const v3 V = -rayDir;
-                    float w[3]; bs.ComputeLobeWeights(svec, V, gs.ExtFlags, w);
-                    float rnd[4];
-                    rnd[0] = rng_float(rng); rnd[1] = rng_float(rng); rnd[2] = rng_float(rng); rnd[3] = rng_float(rng);   // GetFloat4, :330
-                    v3 L; int lobe;
-                    if (bs.Sample(svec, V, w, rnd, L, lobe)) {
-                        float pdf; v3 f;
-                        bs.EvaluateLobe(svec, L, V, w, lobe, gs.ExtFlags, pdf, f);
-                        if (pdf != 0.0f && !(f.x == 0.0f && f.y == 0.0f && f.z == 0.0f)) {       // :336,342
-                            thr = thr * V3(f.x / pdf, f.y / pdf, f.z / pdf);                     // :346
-                            bool survive = true;
-                            if (gs.IsRussianRouletteEnabled && bounce > 3) {                     // :348-356
-                                const float p = fmaxf(thr.x, fmaxf(thr.y, thr.z));
-                                if (rng_float(rng) >= p) survive = false;
-                                else thr = V3(thr.x / p, thr.y / p, thr.z / p);
-                            }
-                            if (survive && !(ml_luminance(thr) <= gs.ThroughputThreshold)        // :361
-                                && bounce < gs.Bounces) {                                        // loop bound, :213
-                                continues = true;
-                                newO = safe_world_ray_origin(h.Position, h.FlatNormal, h.PositionOffset, L);   // :221
-                                newD = L;
-                                bounce++;
-                            }
-                        }
-                    }
-                }
-                if (continues) { alive = true; break; }
-                rsum = rsum + srad;                                        // :372
-                sample++;
-                if (sample < gs.SamplesPerPixel) { thr = V3(1, 1, 1); srad = V3(0, 0, 0); continue; }
-                // pixel finished: :377-386
-                v3 out = V3(0, 0, 0);
-                if (finite3(rsum)) { const float ns = (float)gs.SamplesPerPixel; out = V3(rsum.x / ns, rsum.y / ns, rsum.z / ns); }
-                ((ushort4*)tx.Radiance)[pixel] = make_ushort4(f32_to_f16(out.x), f32_to_f16(out.y), f32_to_f16(out.z), 0);
-                if (tx.RadianceF32) ((float4*)tx.RadianceF32)[pixel] = make_float4(out.x, out.y, out.z, 0.0f);
-                break;
-            }
+            const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
+            const v3 rayDir = primaryRay.d;
+            const float4 pos = ((const float4*)tx.Position)[pixel];
+            const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
+            const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
+            const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
+            const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
+            SurfaceHit h;
+            h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;                  // HitInfo.hlsli:67-79
+            h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
+            h.GeometricNormal = oct_decode(snorm16_to_f32(ge.x), snorm16_to_f32(ge.y));
+            h.ShadingNormal = V3(snorm16_to_f32(nr.x), snorm16_to_f32(nr.y), snorm16_to_f32(nr.z));
+            h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
+            const v3 emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));           // :119,197
+            const float metal = unorm8_to_f32(bcm.w);
+            const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
+            const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
+            BSDFSample bs;
+            bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
+            if (scatter(gs, p, h, bs, emission, rayDir, newO, newD)) toTraced = true;
+            else toFresh = end_sample(gs, tx, p);
         }
-        // compaction of the surviving paths into the same sub-queue of the output queue
-        const uint32_t slot = sq * segCap + block_reserve(alive, &countOut[sq], lds);
-        if (alive) {
-            qout.s0[slot] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pixel));
-            qout.s1[slot] = make_float4(srad.x, srad.y, srad.z, __uint_as_float(rng));
-            qout.s2[slot] = make_float4(rsum.x, rsum.y, rsum.z, __uint_as_float((sample << 16) | (bounce << 1)));
-            qout.r0[slot] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
-            qout.r1[slot] = make_float4(newD.x, newD.y, newD.z, INFINITY);                // TMax = inf, :224
+        const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
+        const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
+        if (toTraced) {
+            store_path(qout, seg + st, p);
+            qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);
+            qout.r1[seg + st] = make_float4(newD.x, newD.y, newD.z, INFINITY);
         }
+        if (toFresh) store_path(qout, seg + (segCap - 1u - sf), p);
     }
 }
 
@@ -567,20 +612,23 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     c.lastIterations = 0;
     if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
     // every wavefront round traces at most one ray per path, a pixel traces at most spp*Bounces rays
-    const uint32_t rounds = gs.SamplesPerPixel * gs.Bounces;
+    // a round = one k_shade + one k_extend. Per sample a path spends one round as "fresh" (bounce 0, no ray) and at
+    // most Bounces rounds as "traced": spp * (Bounces + 1) rounds empty every queue.
+    const uint32_t rounds = gs.SamplesPerPixel * (gs.Bounces + 1u);
     const uint32_t tiles = (npix + 255u) / 256u;
     const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
-    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * kSubQueues);
+    const uint32_t cstride = 2u * kSubQueues;                                  // traced + fresh counters per round
+    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * cstride);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * kSubQueues, c.stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * cstride, c.stream)) != hipSuccess) return e;
     const uint32_t grid = persistent_grid(c.device);
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], segCap, &c.queueCounts[0]);
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+        uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        uint32_t* cin = &c.queueCounts[r * kSubQueues]; uint32_t* cout = &c.queueCounts[(r + 1) * kSubQueues];
         if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
         else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
