@@ -86,6 +86,11 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="frames in flight per GPU: independent contexts on separate HIP streams, so the launch-bound tail "
+                         "rounds of one frame overlap the wide rounds of the next")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="developer aid: render only rank 0's share of an N-rank sharding on one GPU (no gather), to see the per-rank frame time")
     args = ap.parse_args()
 
     import torch
@@ -110,28 +115,39 @@ def main():
 
     kind, W, H, spp, bounces, desc = WORKLOADS[args.workload]
     scene, ext = make_scene(kind, W / H, S)
-    stream = torch.cuda.current_stream(device)
-    ctx = P.DeviceContext(local_rank, stream=stream.cuda_stream)
-    ctx.set_sharding(rank, world, BAND)
-    gpu_scene = P.Scene(ctx, scene, device)
-    renderer = P.Renderer(ctx, gpu_scene, W, H)
     max_rows = max(P.local_rows(H, r, world, BAND) for r in range(world))
-    if world > 1:                                           # equal-sized gather pieces
-        renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
-        for op in (renderer.gbuffer, renderer.raytracing):
-            op.Textures = renderer.textures
-    full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if rank == 0 else None
-    gathered_flat = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and world > 1) else None
     offsets = (np.arange(world, dtype=np.uint64) * np.uint64(max_rows * W * 8))
 
+    class Lane:
+        """One frame in flight: its own HIP stream, library context (queues, BVH copy) and G-buffer textures."""
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(self.stream):
+                self.ctx = P.DeviceContext(local_rank, stream=self.stream.cuda_stream)
+                self.ctx.set_sharding(rank, args.emulate_world if args.emulate_world else world, BAND)
+                self.scene = P.Scene(self.ctx, scene, device)
+                self.renderer = P.Renderer(self.ctx, self.scene, W, H)
+                if world > 1:                                   # equal-sized gather pieces
+                    self.renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
+                    for op in (self.renderer.gbuffer, self.renderer.raytracing):
+                        op.Textures = self.renderer.textures
+                self.full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if rank == 0 else None
+                self.gathered = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and world > 1) else None
+            self.stream.synchronize()
+
+    lanes = [Lane() for _ in range(max(1, args.inflight))]
+    ctx = lanes[0].ctx
+
     def step(frame_index):
+        lane = lanes[frame_index % len(lanes)]
         gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame_index, ext_flags=ext)
-        renderer.render(gs)
-        if world > 1:
-            SH.gather_to_root(renderer.textures["Radiance"], rank, world, dist, out=gathered_flat)
-            if rank == 0:
-                ctx.check(ctx.lib.pt_deinterleave_bands(ctx.handle, full.data_ptr(), gathered_flat.data_ptr(), offsets.ctypes.data,
-                                                        world, BAND, W, H, 8))
+        with torch.cuda.stream(lane.stream):
+            lane.renderer.render(gs)
+            if world > 1:
+                SH.gather_to_root(lane.renderer.textures["Radiance"], rank, world, dist, out=lane.gathered)
+                if rank == 0:
+                    lane.ctx.check(lane.ctx.lib.pt_deinterleave_bands(lane.ctx.handle, lane.full.data_ptr(), lane.gathered.data_ptr(),
+                                                                      offsets.ctypes.data, world, BAND, W, H, 8))
         return gs
 
     def barrier():
@@ -143,28 +159,31 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    ctx.reset_counters()
-    timing = world == 1
-    if timing:
-        ctx.enable_kernel_timing(True)
+    timing = world == 1 and not args.emulate_world          # HIP events around every extend / shade launch (library side)
+    for lane in lanes:
+        lane.ctx.reset_counters()
+        if timing:
+            lane.ctx.enable_kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         gs = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    c = ctx.counters()
-    kt = ctx.kernel_timing() if timing else None
-    ctx.enable_kernel_timing(False)
+    counters = [lane.ctx.counters() for lane in lanes]
+    kts = [lane.ctx.kernel_timing() for lane in lanes] if timing else None
+    for lane in lanes:
+        lane.ctx.enable_kernel_timing(False)
+    primary = sum(c.PrimaryRays for c in counters); secondary = sum(c.SecondaryRays for c in counters)
 
-    rays_local = float(c.PrimaryRays + c.SecondaryRays)
-    t = torch.tensor([elapsed, rays_local, float(c.SecondaryRays)], dtype=torch.float64, device=device)
+    rays_local = float(primary + secondary)
+    t = torch.tensor([elapsed, rays_local, float(secondary)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, rays_total, secondary_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
     else:
-        rays_total, secondary_total = rays_local, float(c.SecondaryRays)
+        rays_total, secondary_total = rays_local, float(secondary)
 
     result = None
     if rank == 0:
@@ -176,7 +195,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frames_per_s": args.steps / elapsed, "mrays_per_s_per_gpu": rays_total / elapsed / 1e6 / world,
             "rays_per_frame": rays_total / args.steps,
-            "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces,
+            "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes),
                        "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
                        "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py)"},
@@ -184,9 +203,11 @@ def main():
 
     # ---- roofline of the dominant kernel (N = 1): one extra frame with traversal statistics for B_bvh
     if rank == 0 and timing:
+        kt = {k: sum(x[k] for x in kts) for k in kts[0]}
         ctx.set_debug_flags(1)
         ctx.reset_counters()
-        step(args.warmup + args.steps - 1)
+        with torch.cuda.stream(lanes[0].stream):
+            lanes[0].renderer.render(gs)
         cs = ctx.counters()
         ctx.set_debug_flags(0)
         rays_frame = max(1, cs.SecondaryRays)
@@ -222,15 +243,17 @@ def main():
             "tris_per_ray": cs.TrianglesTested / float(cs.PrimaryRays + cs.SecondaryRays),
             "other_kernel": {k: {"ms_total": v["ms"], "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
                              for k, v in kernels.items() if k != dom},
-            "note": "event time summed over the timed steps; bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
+            "note": "HIP-event time summed over every launch of the timed steps (all frames in flight, so a launch shares the GPU with "
+                    "the other lane's kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
         }
         del rays_frame
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
 
     if rank == 0:
         print(json.dumps(result))
-    ctx.close()
+    for lane in lanes:
+        lane.ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

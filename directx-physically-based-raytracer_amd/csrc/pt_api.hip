@@ -82,6 +82,8 @@ void pt_destroy(PtContext* ctx)
         void* ptrs[6] = { q.s0, q.s1, q.s2, q.r0, q.r1, q.hit };
         for (void* p : ptrs) if (p) hipFree(p);
     }
+    if (c.graphExec) hipGraphExecDestroy(c.graphExec);
+    if (c.frameConstants) hipFree(c.frameConstants);
     if (c.queueCounts) hipFree(c.queueCounts);
     if (c.counters) hipFree(c.counters);
     for (auto e : c.evExtend) hipEventDestroy(e);
@@ -359,7 +361,7 @@ int pt_gbuffer_render(PtContext* ctx, const PtGBufferConstants* constants, const
     Context& c = ctx->c;
     API_ARG(&c, constants && textures, "constants / textures is NULL");
     API_HIP(&c, hipSetDevice(c.device));
-    SceneView sv; FrameView fv;
+    SceneView sv; FrameView fv; memset(&sv, 0, sizeof sv); memset(&fv, 0, sizeof fv);
     int s = make_views(c, constants->RenderSize[0], constants->RenderSize[1], sv, fv);
     if (s != PT_OK) return s;
     API_HIP(&c, launch_gbuffer(c, sv, fv, constants->Flags, *textures));
@@ -385,7 +387,7 @@ int pt_raytrace_render(PtContext* ctx, const PtTextures* tx)
     API_ARG(&c, tx->Position && tx->FlatNormal && tx->GeometricNormal && tx->BaseColorMetalness && tx->NormalRoughness && tx->IOR
                  && tx->Transmission && tx->Radiance, "a G-buffer texture the path tracer reads is not bound (Raytracing::Textures)");
     API_HIP(&c, hipSetDevice(c.device));
-    SceneView sv; FrameView fv;
+    SceneView sv; FrameView fv; memset(&sv, 0, sizeof sv); memset(&fv, 0, sizeof fv);
     int s = make_views(c, c.settings.RenderSize[0], c.settings.RenderSize[1], sv, fv);
     if (s != PT_OK) return s;
     if (c.settings.Bounces == 0) return PT_OK;          // reference: the pass is not dispatched, Source/App.cpp:1277-1279

@@ -54,6 +54,8 @@ struct PathQueue {
     uint4*  hit;     // instance | triangle slot in the BLAS | u bits | v bits      (instance ~0u = miss)
 };
 
+struct FrameConstants { PtCamera cam; PtSceneData sd; PtGraphicsSettings gs; };
+
 struct DeviceCounters {
     unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
     unsigned int mismatchCount, _pad;        // PT_DEBUG_BRUTE_FORCE: rays whose LBVH result differs from brute force
@@ -82,6 +84,8 @@ struct Context {
     void* blobDev = nullptr; BlobView blob{};        // compact traversal copy of TLAS + instances + every referenced BLAS
 
     PathQueue queue[2]{}; uint32_t queueCapacity = 0;
+    FrameConstants* frameConstants = nullptr;
+    hipGraphExec_t graphExec = nullptr; std::string graphKey; bool disableGraphs = false;
     uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;
     DeviceCounters* counters = nullptr;
     uint64_t lastIterations = 0;

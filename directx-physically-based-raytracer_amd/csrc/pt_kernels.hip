@@ -277,6 +277,15 @@ PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
     return base + prefix;
 }
 
+// Per-frame constants (camera, scene data, settings) live in a device buffer written in stream order by
+// k_set_constants, not in kernel arguments: the frame's launch sequence can then be captured once into a
+// hipGraph and replayed for every frame (FrameIndex, jitter, ... change without touching the graph).
+__global__ void k_set_constants(FrameConstants v, FrameConstants* dst)
+{
+    const uint32_t* s = (const uint32_t*)&v; uint32_t* d = (uint32_t*)dst;
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameConstants) / 4; i += blockDim.x) d[i] = s[i];
+}
+
 // Queue regions. Every sub-queue segment holds two kinds of entries, grown from its two ends:
 //   traced  [0, nT)                 paths whose ray has been traced by k_extend: state + ray + hit record
 //   fresh   (segCap-1 ... segCap-nF] paths about to start a sample at the primary surface: state only
@@ -285,9 +294,10 @@ PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
 // RNG state (all samples of a pixel draw from one stream, Raytracing.hlsl:108,191).
 
 // enqueue every primary-hit pixel as fresh (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
-__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, PtGraphicsSettings gs, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* countFresh)
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* countFresh)
 {
     __shared__ uint32_t lds[8];
+    const PtGraphicsSettings& gs = fc->gs;
     const uint32_t npix = fv.width * fv.localRows;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     for (uint32_t j = bq; (j * kSubQueues + sq) * 256u < npix; j += nbq) {
@@ -370,10 +380,11 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, PathR
 
 // counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
 template <bool TEXTURED>
-__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, PtGraphicsSettings gs, PtTextures tx,
+__global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
     __shared__ uint32_t lds[8];
+    const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
     const uint32_t seg = sq * segCap;
@@ -605,32 +616,21 @@ static void timing_begin(Context& c, std::vector<hipEvent_t>& ev, uint32_t k)
 }
 static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if (c.timing) hipEventRecord(ev[2 * k + 1], c.stream); }
 
-hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx)
+// the launch sequence of one frame: counters reset, k_pt_init, then the shade / extend rounds
+static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
-    const PtGraphicsSettings& gs = c.settings;
-    const uint32_t npix = fv.width * fv.localRows;
-    c.lastIterations = 0;
-    if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
-    // every wavefront round traces at most one ray per path, a pixel traces at most spp*Bounces rays
-    // a round = one k_shade + one k_extend. Per sample a path spends one round as "fresh" (bounce 0, no ray) and at
-    // most Bounces rounds as "traced": spp * (Bounces + 1) rounds empty every queue.
-    const uint32_t rounds = gs.SamplesPerPixel * (gs.Bounces + 1u);
-    const uint32_t tiles = (npix + 255u) / 256u;
-    const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
     const uint32_t cstride = 2u * kSubQueues;                                  // traced + fresh counters per round
-    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * cstride);
-    if (e != hipSuccess) return e;
+    hipError_t e;
     if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * cstride, c.stream)) != hipSuccess) return e;
-    const uint32_t grid = persistent_grid(c.device);
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, gs, tx, c.queue[0], segCap, &c.queueCounts[kSubQueues]);
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
-        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, gs, tx, qin, qout, segCap, cin, cout);
+        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, segCap, cin, cout);
+        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, segCap, cin, cout);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
@@ -649,8 +649,55 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         }
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }
-    c.lastIterations = rounds + 1;
     return hipGetLastError();
+}
+
+template <typename T> static void key_add(std::string& k, const T& v) { k.append((const char*)&v, sizeof v); }
+
+hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx)
+{
+    const PtGraphicsSettings& gs = c.settings;
+    const uint32_t npix = fv.width * fv.localRows;
+    c.lastIterations = 0;
+    if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
+    // a round = one k_shade + one k_extend. Per sample a path spends one round as "fresh" (bounce 0, no ray) and at
+    // most Bounces rounds as "traced": spp * (Bounces + 1) rounds empty every queue.
+    const uint32_t rounds = gs.SamplesPerPixel * (gs.Bounces + 1u);
+    const uint32_t tiles = (npix + 255u) / 256u;
+    const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
+    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * 2u * kSubQueues);
+    if (e != hipSuccess) return e;
+    if (!c.frameConstants && (e = hipMalloc((void**)&c.frameConstants, sizeof(FrameConstants))) != hipSuccess) return e;
+    FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
+    k_set_constants<<<1, 192, 0, c.stream>>>(fc, c.frameConstants);
+    const uint32_t grid = persistent_grid(c.device);
+    c.lastIterations = rounds + 1;
+
+    // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
+    const bool graphable = c.stream != nullptr && !c.timing && c.debugFlags == 0 && !c.disableGraphs;
+    if (graphable) {
+        std::string key;
+        key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
+        key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
+        key_add(key, c.frameConstants); key_add(key, c.stream);
+        if (key != c.graphKey || !c.graphExec) {
+            if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }
+            c.graphKey.clear();
+            hipGraph_t graph = nullptr;
+            e = hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed);
+            if (e == hipSuccess) {
+                hipError_t e2 = enqueue_frame(c, sv, fv, tx, rounds, segCap, grid);
+                e = hipStreamEndCapture(c.stream, &graph);
+                if (e == hipSuccess) e = e2;
+            }
+            if (e == hipSuccess) e = hipGraphInstantiate(&c.graphExec, graph, nullptr, nullptr, 0);
+            if (graph) hipGraphDestroy(graph);
+            if (e != hipSuccess) { c.graphExec = nullptr; c.disableGraphs = true; (void)hipGetLastError(); }
+            else c.graphKey = key;
+        }
+        if (c.graphExec) return hipGraphLaunch(c.graphExec, c.stream);
+    }
+    return enqueue_frame(c, sv, fv, tx, rounds, segCap, grid);
 }
 
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsDev, uint32_t rankCount,

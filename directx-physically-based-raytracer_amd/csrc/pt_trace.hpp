@@ -91,6 +91,18 @@ PT_DEV RaySetup ray_setup(v3 d)
     return r;
 }
 
+// The paper's fp64 fallback, kept out of line: taken only when an edge function is exactly 0 (a ray through an
+// edge or vertex). Inlined, hipcc if-converts it and every triangle test pays 18 fp64 instructions.
+__device__ __attribute__((noinline)) void tri_edge_fallback(float Ax, float Ay, float Bx, float By, float Cx, float Cy, float& U, float& V, float& W)
+{
+    double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+    U = (float)(CxBy - CyBx);
+    double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+    V = (float)(AxCy - AyCx);
+    double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+    W = (float)(BxAy - ByAx);
+}
+
 // Per-triangle part; fp64 recomputation of the edge functions when one is exactly 0 (paper's
 // fallback) keeps shared edges watertight. Returns t,u,v (u weights v1, v weights v2: DXR barycentrics).
 PT_DEV bool tri_test(const RaySetup& r, v3 o, v3 v0, v3 v1, v3 v2, float& t, float& u, float& v)
@@ -103,14 +115,7 @@ PT_DEV bool tri_test(const RaySetup& r, v3 o, v3 v0, v3 v1, v3 v2, float& t, flo
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
-    if (U == 0.0f || V == 0.0f || W == 0.0f) {
-        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
-        U = (float)(CxBy - CyBx);
-        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
-        V = (float)(AxCy - AyCx);
-        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
-        W = (float)(BxAy - ByAx);
-    }
+    if (__builtin_expect(U == 0.0f || V == 0.0f || W == 0.0f, 0)) tri_edge_fallback(Ax, Ay, Bx, By, Cx, Cy, U, V, W);
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     float det = U + V + W;
     if (det == 0.0f) return false;
@@ -145,7 +150,7 @@ struct AlphaContext {
     const struct InstanceRecord* instances;
 };
 
-PT_DEV bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
+__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
 
 // commit() for a candidate of a geometry without D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE: the alpha test runs only
 // for candidates that would otherwise be committed (DXR reports candidates inside the current ray interval).
@@ -187,7 +192,7 @@ PT_DEV float safe_inv1(float d)
 PT_DEV v3 safe_inv(v3 d) { return V3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
 
 // TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
-PT_DEV bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
+__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
 {
     const PtObjectData* od = &ac.objects[ac.instances[inst].instanceID + geom];
     TexCoords tc;
