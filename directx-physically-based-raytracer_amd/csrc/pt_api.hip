@@ -326,12 +326,8 @@ int pt_deinterleave_bands(PtContext* ctx, void* dst_full, const void* gathered, 
     API_ARG(&c, dst_full && gathered && rank_offsets_host && rank_count >= 1 && band_height >= 1, "invalid de-interleave arguments");
     API_ARG(&c, pixel_bytes % 4 == 0, "pixel size must be a multiple of 4 bytes");
     API_HIP(&c, hipSetDevice(c.device));
-    uint64_t* dOff = nullptr;
-    API_HIP(&c, hipMalloc((void**)&dOff, sizeof(uint64_t) * rank_count));
-    hipError_t e = hipMemcpyAsync(dOff, rank_offsets_host, sizeof(uint64_t) * rank_count, hipMemcpyHostToDevice, c.stream);
-    if (e == hipSuccess) e = launch_deinterleave(c.stream, dst_full, gathered, dOff, rank_count, band_height, width, height, pixel_bytes);
-    hipStreamSynchronize(c.stream);
-    hipFree(dOff);
+    API_ARG(&c, rank_count <= 64, "at most 64 ranks");
+    hipError_t e = launch_deinterleave(c.stream, dst_full, gathered, rank_offsets_host, rank_count, band_height, width, height, pixel_bytes);
     if (e != hipSuccess) return fail_hip(&c, e, "de-interleave");
     return PT_OK;
 }

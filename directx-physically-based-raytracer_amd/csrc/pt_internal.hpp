@@ -106,7 +106,7 @@ hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, 
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);
 hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx);
-hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsDev, uint32_t rankCount,
+hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 
 } // namespace pt

@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256) void k_extend(AccelView av, AlphaContext ac, P
 __global__ void k_count_primary(DeviceCounters* counters, unsigned long long n) { atomicAdd(&counters->primaryRays, n); }
 
 // dst[y][x] <- gathered per-rank band buffers (PtSharding layout)
-__global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, const uint64_t* rankOffsets, uint32_t rankCount, uint32_t bandHeight,
+struct RankOffsets { uint64_t v[64]; };              // by value in the kernel arguments: no allocation, no copy, no sync
+
+__global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, RankOffsets rankOffsets, uint32_t rankCount, uint32_t bandHeight,
                                uint32_t width, uint32_t height, uint32_t pixelBytes)
 {
     const uint64_t rowBytes = (uint64_t)width * pixelBytes, chunks = rowBytes / 4;
@@ -559,7 +561,7 @@ __global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, const uint64_t*
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t y = (uint32_t)(t / chunks); const uint64_t cx = t % chunks;
         const uint32_t band = y / bandHeight, rank = band % rankCount, localRow = (band / rankCount) * bandHeight + (y - band * bandHeight);
-        ((uint32_t*)(dst + (uint64_t)y * rowBytes))[cx] = ((const uint32_t*)(src + rankOffsets[rank] + (uint64_t)localRow * rowBytes))[cx];
+        ((uint32_t*)(dst + (uint64_t)y * rowBytes))[cx] = ((const uint32_t*)(src + rankOffsets.v[rank] + (uint64_t)localRow * rowBytes))[cx];
     }
 }
 
@@ -700,10 +702,12 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     return enqueue_frame(c, sv, fv, tx, rounds, segCap, grid);
 }
 
-hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsDev, uint32_t rankCount,
+hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes)
 {
-    k_deinterleave<<<2048, 256, 0, stream>>>((uint8_t*)dst, (const uint8_t*)src, rankOffsetsDev, rankCount, bandHeight, width, height, pixelBytes);
+    RankOffsets ro;
+    for (uint32_t r = 0; r < 64; r++) ro.v[r] = r < rankCount ? rankOffsetsHost[r] : 0;
+    k_deinterleave<<<1024, 256, 0, stream>>>((uint8_t*)dst, (const uint8_t*)src, ro, rankCount, bandHeight, width, height, pixelBytes);
     return hipGetLastError();
 }
 
