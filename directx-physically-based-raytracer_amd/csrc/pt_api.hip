@@ -122,7 +122,7 @@ int pt_heap_set_buffer(PtContext* ctx, uint32_t descriptor, const void* device_p
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     Context& c = ctx->c;
     API_ARG(&c, descriptor < c.heapHost.size(), "descriptor index beyond pt_heap_resize");
-    API_ARG(&c, stride == 0 || stride == 2 || stride == 4, "typed buffer stride must be 0 (raw), 2 or 4");
+    API_ARG(&c, stride == 0 || stride == 2 || stride == 4 || stride == 8, "buffer stride must be 0 (raw), 2 / 4 (typed index buffer) or 8 (structured half4 motion vectors)");
     c.heapHost[descriptor] = HeapEntry{ device_ptr, bytes, stride, kKindBuffer };
     c.heapDirty = true;
     return PT_OK;
@@ -187,6 +187,42 @@ int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint
     uint64_t id = c.nextBlasId++;
     c.blas[id] = b;
     *out_blas_id = id;
+    return PT_OK;
+}
+
+int pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags)
+{
+    (void)build_flags;
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    auto it = c.blas.find(blas_id);
+    API_ARG(&c, it != c.blas.end(), "unknown bottom-level id");
+    API_ARG(&c, geometries || geometry_count == 0, "geometries is NULL");
+    for (uint32_t g = 0; g < geometry_count; g++) {
+        API_ARG(&c, geometries[g].IndexStride == 2 || geometries[g].IndexStride == 4, "Triangle index format must be either uint16 or uint32");
+        API_ARG(&c, geometries[g].IndexCount % 3 == 0, "Triangle index count must be divisible by 3");
+    }
+    API_HIP(&c, hipSetDevice(c.device));
+    // PERFORM_UPDATE (Source/Scene.ixx:327-341, CommandList::UpdateAccelerationStructures): the skinned vertices moved.
+    // The LBVH is rebuilt (Morton order may change) under the same id; a device build of a skinned mesh is cheaper than
+    // keeping a stale topology. The TLAS must be rebuilt afterwards (pt_build_top_level), as the reference does.
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    Blas b;
+    hipError_t e = build_blas_device(geometries, geometry_count, c.stream, b);
+    if (e != hipSuccess) { free_blas(b); return fail_hip(&c, e, "bottom-level update"); }
+    free_blas(it->second);
+    it->second = b;
+    c.haveTlas = false;                                  // instance records point at the freed BLAS
+    return PT_OK;
+}
+
+int pt_skin_mesh(PtContext* ctx, const void* skeletal_vertices, const float* skeletal_transforms, void* vertices, void* motion_vectors, uint32_t vertex_count)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_ARG(&c, vertex_count == 0 || (skeletal_vertices && skeletal_transforms && vertices && motion_vectors), "a skinning buffer is NULL");
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, launch_skin(c.stream, skeletal_vertices, skeletal_transforms, vertices, motion_vectors, vertex_count));
     return PT_OK;
 }
 

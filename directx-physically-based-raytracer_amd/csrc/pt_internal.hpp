@@ -103,6 +103,9 @@ struct BlobPiece { const BvhNode* nodes; const TriPacket* tris; uint32_t nodeCou
 hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, const std::vector<BlobPiece>& pieces,
                              const std::vector<uint32_t>& pieceOfInstance, hipStream_t stream, void** outDev, BlobView* outView);
 
+// pt_skin.hip
+hipError_t launch_skin(hipStream_t stream, const void* skeletal, const float* transforms, void* vertices, void* motion, uint32_t count);
+
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);
 hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx);

@@ -200,6 +200,17 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
                 v3 prev = h.Position;
                 if (!sd.IsStatic && sv.instanceData) {
                     const float* P = sv.instanceData[h.InstanceIndex].PreviousObjectToWorld; v3 q = h.ObjectPosition;
+                    const PtMeshDescriptors md = sv.objects[h.ObjectIndex].MeshDescriptors;
+                    if (md.MotionVectors != ~0u) {              // :73-84, StructuredBuffer<float16_t4>
+                        const uint16_t* mvb = (const uint16_t*)sv.heap[md.MotionVectors].ptr;
+                        const HeapEntry ib = sv.heap[md.Indices];
+                        v3 m3[3];
+                        for (int kk = 0; kk < 3; kk++) {
+                            const uint32_t vi = load_index_dev(ib.ptr, ib.stride, 3 * h.PrimitiveIndex + kk);
+                            m3[kk] = V3(f16_to_f32(mvb[4 * (size_t)vi]), f16_to_f32(mvb[4 * (size_t)vi + 1]), f16_to_f32(mvb[4 * (size_t)vi + 2]));
+                        }
+                        q = q + ((m3[0] + (m3[1] - m3[0]) * hit.u) + (m3[2] - m3[0]) * hit.v);
+                    }
                     prev = V3(P[0] * q.x + P[1] * q.y + P[2] * q.z + P[3], P[4] * q.x + P[5] * q.y + P[6] * q.z + P[7], P[8] * q.x + P[9] * q.y + P[10] * q.z + P[11]);
                 }
                 float clip[4], view[4];

@@ -14,6 +14,11 @@ VERTEX = np.dtype({  # VertexPositionNormalTangentTexture, 32 B
     "formats": [("<f4", 3), ("<i2", 3), ("<i2", 3), ("<f2", 2), ("<f2", 2)],
     "offsets": [0, 12, 18, 24, 28], "itemsize": 32})
 
+SKELETAL_VERTEX = np.dtype({  # VertexPositionNormalTangentSkin, 48 B (Source/Vertex.ixx:52-57)
+    "names": ["Position", "Normal", "Tangent", "Joints", "Weights"],
+    "formats": [("<f4", 3), ("<i2", 3), ("<i2", 3), ("<u2", 4), ("<f4", 4)],
+    "offsets": [0, 12, 18, 24, 32], "itemsize": 48})
+
 VERTEX_DESC = np.dtype({
     "names": ["Stride", "Normal", "Tangent", "TexCoord"],
     "formats": ["<u4", "<u4", "<u4", ("<u4", 2)],

@@ -20,7 +20,7 @@ _LIB = None
 
 EXPORTS = [
     "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync",
-    "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_release_bottom_level",
+    "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_reset_counters", "pt_get_counters",
@@ -92,6 +92,8 @@ def load_library():
         lib.pt_heap_set_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.pt_build_bottom_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         lib.pt_release_bottom_level.argtypes = [C.c_void_p, C.c_uint64]
+        lib.pt_update_bottom_level.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.pt_skin_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         lib.pt_build_top_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.pt_get_accel_stats.argtypes = [C.c_void_p, C.c_void_p]
         for f in (lib.pt_set_camera, lib.pt_set_scene_data, lib.pt_set_sharding, lib.pt_raytrace_set_constants,
@@ -231,7 +233,37 @@ class Scene:
         ctx.check(lib.pt_set_instance_data(ctx.handle, C.c_void_p(self.instance_data.data_ptr()), len(scene.instance_data)))
         self._heap_dev = heap_dev
         self.blas_ids = []
+        self._skin_cache = {}
         self.CreateAccelerationStructures()
+
+    def SkinSkeletalMeshes(self, mesh, skeletal_transforms):
+        """Scene::SkinSkeletalMeshes (Source/Scene.ixx:233-280) for one mesh: joint transforms -> SkeletalMeshSkinning."""
+        ctx, lib = self.ctx, self.ctx.lib
+        hv = next(h for m, h, _ in self.desc.geometry if m is mesh)
+        hm = int(self.desc._motion_heap[id(mesh)])
+        if id(mesh) not in self._skin_cache:
+            self._skin_cache[id(mesh)] = to_device(mesh.skeletal_vertices, self.device)
+        tr = to_device(np.ascontiguousarray(skeletal_transforms, np.float32), self.device)
+        self._buffers.append(tr)
+        ctx.check(lib.pt_skin_mesh(ctx.handle, C.c_void_p(self._skin_cache[id(mesh)].data_ptr()), C.c_void_p(tr.data_ptr()),
+                                   C.c_void_p(self._heap_dev[hv].data_ptr()), C.c_void_p(self._heap_dev[hm].data_ptr()), len(mesh.vertices)))
+
+    def UpdateAccelerationStructures(self, node_index):
+        """the PERFORM_UPDATE branch of Scene::CreateAccelerationStructures (Source/Scene.ixx:327-345) + TLAS rebuild."""
+        ctx, scene, lib = self.ctx, self.desc, self.ctx.lib
+        first, count = scene.blas[node_index]
+        geoms = (GeometryDesc * max(1, count))()
+        for g in range(count):
+            mesh, hv, hi = scene.geometry[first + g]
+            d = geoms[g]
+            d.VertexBuffer = self._heap_dev[hv].data_ptr(); d.VertexCount, d.VertexStride = len(mesh.vertices), mesh.vertices.dtype.itemsize
+            d.IndexBuffer = self._heap_dev[hi].data_ptr(); d.IndexCount, d.IndexStride = mesh.indices.size, mesh.indices.dtype.itemsize
+            d.Flags = 1
+        ctx.check(lib.pt_update_bottom_level(ctx.handle, self.blas_ids[node_index], C.addressof(geoms), count, 0x9))
+        self._build_top_level()
+
+    def download(self, heap_index, dtype):
+        return self._heap_dev[heap_index].cpu().numpy().view(dtype)
 
     def CreateAccelerationStructures(self):
         """Scene::CreateAccelerationStructures (Source/Scene.ixx:286-380)."""
@@ -253,6 +285,10 @@ class Scene:
             bid = C.c_uint64(0)
             ctx.check(lib.pt_build_bottom_level(ctx.handle, C.addressof(geoms), count, 0x4, C.byref(bid)))
             self.blas_ids.append(bid.value)
+        self._build_top_level()
+
+    def _build_top_level(self):
+        ctx, scene, lib = self.ctx, self.desc, self.ctx.lib
         n = len(scene.objects)
         descs = (InstanceDesc * max(1, n))()
         for i in range(n):                                        # Scene.ixx:365-377

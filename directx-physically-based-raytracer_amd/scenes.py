@@ -82,6 +82,8 @@ class Mesh:                      # Source/Model.ixx:26-47
     has_tangents: bool = False
     has_uv: tuple = (False, False)
     textures: dict = None        # slot name (TEX_SLOTS) -> (Texture, TextureCoordinateIndex)
+    motion_vectors: np.ndarray = None   # skinned meshes: [n,4] half bits, written by the skinning pass (Model.ixx:33)
+    skeletal_vertices: np.ndarray = None  # L.SKELETAL_VERTEX, Mesh::SkeletalVertices
 
 
 @dataclass
@@ -130,6 +132,7 @@ class Scene:
         """Scene::Refresh + App::UpdateScene: InstanceData / ObjectData / descriptor heap."""
         self.heap, self.geometry, self.blas = [], [], []
         mesh_heap, tex_heap = {}, {}
+        self._motion_heap = {}
 
         def tex_descriptor(tex):
             if id(tex) not in tex_heap:
@@ -146,8 +149,12 @@ class Scene:
                 if key not in mesh_heap:
                     hv = len(self.heap); self.heap.append(HeapItem(mesh.vertices, 0))
                     hi = len(self.heap); self.heap.append(HeapItem(mesh.indices, mesh.indices.dtype.itemsize))
-                    mesh_heap[key] = (hv, hi)
-                self.geometry.append((mesh,) + mesh_heap[key])
+                    hm = L.NONE
+                    if mesh.motion_vectors is not None:
+                        hm = len(self.heap); self.heap.append(HeapItem(mesh.motion_vectors, 8))
+                    mesh_heap[key] = (hv, hi, hm)
+                self.geometry.append((mesh,) + mesh_heap[key][:2])
+                self._motion_heap[key] = mesh_heap[key][2]
             self.blas.append((first, len(node.meshes)))
         if self.env_texture is not None and self.scene_data is not None:
             self.scene_data["EnvironmentLightTextureDescriptor"] = tex_descriptor(self.env_texture)
@@ -177,7 +184,7 @@ class Scene:
                 od["VertexDesc"]["TexCoord"] = (24 if mesh.has_uv[0] else L.NONE, 28 if mesh.has_uv[1] else L.NONE)
                 od["MeshDescriptors"]["Vertices"] = hv
                 od["MeshDescriptors"]["Indices"] = hi
-                od["MeshDescriptors"]["MotionVectors"] = L.NONE
+                od["MeshDescriptors"]["MotionVectors"] = self._motion_heap.get(id(mesh), L.NONE)
                 od["Material"] = mesh.material if mesh.material is not None else L.default_material()
                 od["TextureMapInfoArray"]["Descriptor"] = L.NONE
                 for slot, (tex, uv_index) in (mesh.textures or {}).items():       # App.cpp:1052-1063
@@ -432,6 +439,55 @@ def cornell_box_textured(aspect=16 / 9, env="latlong", seed=7):
         e[2] *= 3.0
         sc.env_texture = Texture(e)
     return sc.finalize()
+
+
+def skinned_bar(segments=12, seed=3):
+    """A square column along +Y bound to two joints (bottom, top) with height-blended weights, plus its skeletal vertex
+    buffer (Model.ixx:31-34, Vertex.ixx:52-57) and a motion-vector buffer: the input of SkeletalMeshSkinning."""
+    pos, nrm, tan, idx = [], [], [], []
+    for side in range(4):
+        a = side * math.pi / 2
+        n = np.array([math.cos(a), 0.0, math.sin(a)]); t = np.array([-math.sin(a), 0.0, math.cos(a)])
+        base = len(pos)
+        for k in range(segments + 1):
+            y = k / segments
+            for e in (-1, 1):
+                pos.append(n * 0.12 + t * 0.12 * e + np.array([0, y, 0])); nrm.append(n); tan.append(t)
+        for k in range(segments):
+            i0 = base + 2 * k
+            idx += [i0, i0 + 2, i0 + 1, i0 + 1, i0 + 2, i0 + 3]
+    pos = np.array(pos, np.float32)
+    vb = make_vertices(pos, np.array(nrm), None, np.array(tan))
+    sk = np.zeros(len(pos), L.SKELETAL_VERTEX)
+    sk["Position"] = pos; sk["Normal"] = vb["Normal"]; sk["Tangent"] = vb["Tangent"]
+    sk["Joints"] = (0, 1, 0, 0)
+    h = pos[:, 1]
+    sk["Weights"] = np.stack([1 - h, h, np.zeros_like(h), np.zeros_like(h)], 1)     # 4th weight is implied: 1 - w0 - w1 - w2
+    mesh = Mesh(vb, make_indices(idx), True, material((0.8, 0.5, 0.2), roughness=0.4), has_tangents=True,
+                motion_vectors=np.zeros((len(pos), 4), np.uint16), skeletal_vertices=sk)
+    return mesh
+
+
+def bar_pose(angle_deg, lift=0.0):
+    """joint transforms (row-major 3x4): joint 0 fixed, joint 1 rotated about Z around the bar's base and lifted."""
+    c, s_ = math.cos(math.radians(angle_deg)), math.sin(math.radians(angle_deg))
+    j0 = np.eye(3, 4)
+    j1 = np.array([[c, -s_, 0, 0], [s_, c, 0, lift], [0, 0, 1, 0]])
+    return np.stack([j0, j1]).astype(np.float32)
+
+
+def dynamic_scene(aspect=16 / 9):
+    """floor + light + a skinned bar: the smallest scene that exercises skinning, BLAS update, TLAS rebuild and
+    per-vertex motion vectors (SceneData.IsStatic = 0)."""
+    white = (0.73, 0.73, 0.73)
+    bar = skinned_bar()
+    nodes = [MeshNode([quad_mesh((-2, 0, -2), (-2, 0, 2), (2, 0, 2), (2, 0, -2), (0, 1, 0), material(white))]),
+             MeshNode([quad_mesh((-0.5, 0, -0.5), (0.5, 0, -0.5), (0.5, 0, 0.5), (-0.5, 0, 0.5), (0, -1, 0),
+                                 material((0.8, 0.8, 0.8), emissive=(1, 1, 1), strength=10.0))]),
+             MeshNode([bar])]
+    objects = [RenderObject(0, trs()), RenderObject(1, trs((0, 2.2, 0))), RenderObject(2, trs((0.1, 0, 0.2), 20.0, (1, 1.2, 1)))]
+    cam = make_camera((0, 0.9, -2.2), forward=(0, -0.1, 1), hfov_deg=70.0, aspect=aspect)
+    return Scene(nodes, objects, cam, make_scene_data((0.05, 0.06, 0.08, 1), is_static=False), name="dynamic").finalize()
 
 
 def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24):

@@ -162,7 +162,8 @@ int  pt_sync(PtContext* ctx);                               /* reference: Comman
 /* ------------------------------------------------------------------------------------------
  * descriptor heap analogue. ObjectData.MeshDescriptors.{Vertices,Indices} index this table
  * (reference: ResourceDescriptorHeap[...], Shaders/RaytracingHelpers.hlsli:82-85).
- * stride: element size of a typed buffer (index buffer: 2 = R16_UINT or 4 = R32_UINT), 0 for raw buffers.
+ * stride: element size of a typed buffer (index buffer: 2 = R16_UINT or 4 = R32_UINT), 0 for raw (vertex) buffers,
+ * 8 for the structured float16_t4 motion-vector buffer of a skinned mesh (MeshDescriptors.MotionVectors).
  * ------------------------------------------------------------------------------------------ */
 int  pt_heap_resize(PtContext* ctx, uint32_t descriptor_count);
 int  pt_heap_set_buffer(PtContext* ctx, uint32_t descriptor, const void* device_ptr, uint64_t bytes, uint32_t stride);
@@ -201,7 +202,18 @@ typedef struct PtGeometryDesc {           /* D3D12_RAYTRACING_GEOMETRY_DESC as f
  * (reference: RTXMU accel-struct id). The LBVH is built on the device, on the context stream. */
 int  pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint32_t geometry_count,
                            uint32_t build_flags, uint64_t* out_blas_id);
-int  pt_release_bottom_level(PtContext* ctx, uint64_t blas_id);       /* Scene::CollectGarbage, Source/Scene.ixx:382-387 */
+/* D3D12_RAYTRACING_ACCELERATION_STRUCTURE_BUILD_FLAG_PERFORM_UPDATE for a skinned mesh node (Source/Scene.ixx:327-341,
+ * CommandList::UpdateAccelerationStructures, Source/CommandList.ixx:235-241): same id, geometry re-read from the (moved)
+ * vertex buffers. Call pt_build_top_level afterwards, as Scene::CreateAccelerationStructures does every dynamic frame. */
+int  pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags);
+int  pt_release_bottom_level(PtContext* ctx, uint64_t blas_id);
+
+/* SkeletalMeshSkinning::Process (Source/SkeletalMeshSkinning.ixx:38-57 -> Shaders/SkeletalMeshSkinning.hlsl:28-62).
+ * skeletal_vertices: VertexPositionNormalTangentSkin[vertex_count] (48 B); skeletal_transforms: row-major float3x4 per
+ * joint; vertices: the mesh's 32-byte vertex buffer (read for the old position, rewritten); motion_vectors: half4 per
+ * vertex (xyz written: old - new object-space position). All device pointers; enqueued on the stream. */
+int  pt_skin_mesh(PtContext* ctx, const void* skeletal_vertices, const float* skeletal_transforms, void* vertices,
+                  void* motion_vectors, uint32_t vertex_count);       /* Scene::CollectGarbage, Source/Scene.ixx:382-387 */
 
 typedef struct PtInstanceDesc {           /* D3D12_RAYTRACING_INSTANCE_DESC as filled at Source/Scene.ixx:365-377 */
     float Transform[12];

@@ -1106,6 +1106,45 @@ static int candidate_is_opaque(const OrScene* s, uint32_t inst, uint32_t geom, u
 }
 
 /* ======================================================================== */
+/* SkeletalMeshSkinning.hlsl:28-62                                           */
+/* ======================================================================== */
+static inline int16_t pack_r16_snorm(float v) { return (int16_t)(clampf(v, -1.0f, 1.0f) * 32767.0f); }   /* Packing.hlsli:3-6: truncating cast */
+
+void or_skin_mesh(const void* skeletal, const float* transforms, void* vertices, uint16_t* motion, uint32_t count)
+{
+    for (uint32_t i = 0; i < count; i++) {
+        const uint8_t* sv = (const uint8_t*)skeletal + 48 * (size_t)i;
+        uint8_t* dv = (uint8_t*)vertices + 32 * (size_t)i;
+        float pos[3], wt[4]; int16_t nq[3], tq[3]; uint16_t joints[4];
+        memcpy(pos, sv, 12); memcpy(nq, sv + 12, 6); memcpy(tq, sv + 18, 6); memcpy(joints, sv + 24, 8); memcpy(wt, sv + 32, 16);
+        const float w[4] = { wt[0], wt[1], wt[2], 1.0f - wt[0] - wt[1] - wt[2] };
+        float M[12] = { 0 };
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 12; k++) M[k] = M[k] + w[j] * transforms[12 * (size_t)joints[j] + k];
+        f3 p = F3(M[0] * pos[0] + M[1] * pos[1] + M[2] * pos[2] + M[3],
+                  M[4] * pos[0] + M[5] * pos[1] + M[6] * pos[2] + M[7],
+                  M[8] * pos[0] + M[9] * pos[1] + M[10] * pos[2] + M[11]);
+        float old[3]; memcpy(old, dv, 12);
+        f3 mv = F3(old[0] - p.x, old[1] - p.y, old[2] - p.z);
+        f3 n = F3(unpack_r16_snorm(nq[0]), unpack_r16_snorm(nq[1]), unpack_r16_snorm(nq[2]));
+        f3 t = F3(unpack_r16_snorm(tq[0]), unpack_r16_snorm(tq[1]), unpack_r16_snorm(tq[2]));
+        f3 r0 = F3(M[0], M[1], M[2]), r1 = F3(M[4], M[5], M[6]), r2 = F3(M[8], M[9], M[10]);
+        /* Math::InverseTranspose Math.hlsli:23-27 */
+        f3 v = cross3(r0, r1);
+        float d = dot3(v, r2);
+        f3 i0 = cross3(r1, r2), i1 = cross3(r2, r0);
+        i0 = F3(i0.x / d, i0.y / d, i0.z / d); i1 = F3(i1.x / d, i1.y / d, i1.z / d); f3 i2 = F3(v.x / d, v.y / d, v.z / d);
+        f3 nn = normalize3(F3(dot3(i0, n), dot3(i1, n), dot3(i2, n)));
+        f3 tt = normalize3(F3(dot3(r0, t), dot3(r1, t), dot3(r2, t)));
+        float np[3] = { p.x, p.y, p.z };
+        memcpy(dv, np, 12);
+        int16_t qn[3] = { pack_r16_snorm(nn.x), pack_r16_snorm(nn.y), pack_r16_snorm(nn.z) };
+        int16_t qt[3] = { pack_r16_snorm(tt.x), pack_r16_snorm(tt.y), pack_r16_snorm(tt.z) };
+        memcpy(dv + 12, qn, 6); memcpy(dv + 18, qt, 6);
+        motion[4 * (size_t)i + 0] = or_f32_to_f16(mv.x); motion[4 * (size_t)i + 1] = or_f32_to_f16(mv.y); motion[4 * (size_t)i + 2] = or_f32_to_f16(mv.z);
+    }
+}
+
+/* ======================================================================== */
 /* CastRay (RaytracingHelpers.hlsli:57-133)                                  */
 /* ======================================================================== */
 typedef struct { f3 Origin, Direction; float TMin, TMax; } RayDesc;
@@ -1259,6 +1298,18 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
                         f3 prev = h.Position;
                         if (!sd->IsStatic) {
                             const float* P = s->inst_data[h.InstanceIndex].PreviousObjectToWorld; f3 q = h.ObjectPosition;
+                            const OrMeshDescriptors* md = &s->objects[h.ObjectIndex].MeshDescriptors;
+                            if (md->MotionVectors != ~0u) {                 /* :73-84, StructuredBuffer<float16_t4> */
+                                const uint16_t* mvb = (const uint16_t*)s->heap[md->MotionVectors].Ptr;
+                                const OrHeapEntry* ib = &s->heap[md->Indices];
+                                f3 m3[3];
+                                for (int kk = 0; kk < 3; kk++) {
+                                    uint32_t vi = load_index(ib->Ptr, ib->Stride, 3 * h.PrimitiveIndex + kk);
+                                    m3[kk] = F3(or_f16_to_f32(mvb[4 * vi]), or_f16_to_f32(mvb[4 * vi + 1]), or_f16_to_f32(mvb[4 * vi + 2]));
+                                }
+                                f3 mi = add3(add3(m3[0], scl3(sub3(m3[1], m3[0]), h.Bary[0])), scl3(sub3(m3[2], m3[0]), h.Bary[1]));
+                                q = add3(q, mi);
+                            }
                             prev = F3(P[0] * q.x + P[1] * q.y + P[2] * q.z + P[3], P[4] * q.x + P[5] * q.y + P[6] * q.z + P[7], P[8] * q.x + P[9] * q.y + P[10] * q.z + P[11]);
                         }
                         float clip[4], view[4];

@@ -211,6 +211,9 @@ void     or_env_term_rtg(const float f0[3], float NoV, float roughness, float ou
 void     or_safe_spawn(const float v[9], const float bary[2], const float o2w[12], const float w2o[12],
                        float objPos[3], float wldPos[3], float objN[3], float wldN[3], float* offset);
 void     or_invert_3x4(const float m[12], float out[12]);
+/* SkeletalMeshSkinning.hlsl:28-62. skeletal: VertexPositionNormalTangentSkin (48 B: pos f32x3, normal i16x3, tangent i16x3,
+ * joints u16x4, weights f32x4); transforms: row-major 3x4 per joint; vertices: 32-B vertex (in/out); motion: half4 per vertex */
+void     or_skin_mesh(const void* skeletal, const float* transforms, void* vertices, uint16_t* motion, uint32_t count);
 /* SampleLevel(sampler, uv, 0) of a heap texture: bilinear, wrap addressing, sRGB decode per texel */
 void     or_texture_sample(const OrHeapEntry* tex, float u, float v, float out[4]);
 void     or_cube_sample(const OrHeapEntry* tex, const float dir[3], float out[4]);

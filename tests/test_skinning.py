@@ -1,0 +1,73 @@
+"""Dynamic scenes: GPU skinning (Shaders/SkeletalMeshSkinning.hlsl:28-62), BLAS update + TLAS rebuild
+(Source/Scene.ixx:327-345), per-vertex motion vectors in the G-buffer (Shaders/GBufferGeneration.hlsl:62-91)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+
+
+def oracle_skin(oracle, mesh, transforms):
+    tr = np.ascontiguousarray(transforms, np.float32)
+    oracle.lib().or_skin_mesh(mesh.skeletal_vertices.ctypes.data, tr.ctypes.data, mesh.vertices.ctypes.data,
+                              mesh.motion_vectors.ctypes.data, len(mesh.vertices))
+
+
+def test_oracle_skinning_known_answers(oracle, pkg):
+    S = pkg.scenes
+    bar = S.skinned_bar()
+    rest = bar.vertices.copy()
+    oracle_skin(oracle, bar, S.bar_pose(0.0))                   # identity pose: nothing moves, motion = 0
+    assert np.array_equal(bar.vertices["Position"], rest["Position"]) and not bar.motion_vectors[:, :3].any()
+    assert np.abs(bar.vertices["Normal"].astype(int) - rest["Normal"].astype(int)).max() <= 1     # truncating re-pack
+    oracle_skin(oracle, bar, S.bar_pose(90.0))
+    top = rest["Position"][:, 1] == 1.0
+    assert top.any()
+    # fully-weighted top vertices are rotated by 90 degrees about Z: (x, 1, z) -> (-1, x, z)
+    assert np.allclose(bar.vertices["Position"][top][:, 0], -1.0, atol=1e-6)
+    assert np.allclose(bar.vertices["Position"][top][:, 1], rest["Position"][top][:, 0], atol=1e-6)
+    bottom = rest["Position"][:, 1] == 0.0
+    assert np.array_equal(bar.vertices["Position"][bottom], rest["Position"][bottom])
+    mv = bar.motion_vectors.view(np.float16)[:, :3].astype(np.float32)
+    assert np.allclose(mv[top], (rest["Position"] - bar.vertices["Position"])[top], atol=2e-3)   # old - new, stored as half
+
+
+@pytest.mark.gpu
+def test_gpu_skinning_update_and_motion_vectors(gpu, ptamd, oracle, pkg):
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 128, 72
+    scene = S.dynamic_scene(aspect=W / H)
+    bar = scene.nodes[2].meshes[0]
+    gpu.set_sharding(0, 1, 16)
+    g = ptamd.Scene(gpu, scene)
+    hv = next(h for m, h, _ in scene.geometry if m is bar)
+    hm = int(scene._motion_heap[id(bar)])
+    r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
+    prev = scene.instance_data["ObjectToWorld"].copy()
+    for step, (angle, lift) in enumerate([(25.0, 0.0), (-40.0, 0.15)]):
+        pose = S.bar_pose(angle, lift)
+        g.SkinSkeletalMeshes(bar, pose)                          # device
+        oracle_skin(oracle, bar, pose)                           # host copy, same bytes expected
+        gpu.sync()
+        assert np.array_equal(g.download(hv, np.uint8), bar.vertices.view(np.uint8).reshape(-1))
+        got_mv = g.download(hm, np.uint16).reshape(-1, 4)
+        assert np.array_equal(got_mv[:, :3], bar.motion_vectors[:, :3])
+        g.UpdateAccelerationStructures(2)                        # BLAS update + TLAS rebuild
+        gs = S.graphics_settings(W, H, spp=2, bounces=4, frame_index=step)
+        for t in r.textures.values():
+            t.zero_()           # miss pixels keep whatever the textures held (as in the reference); the oracle starts from zeros
+        gpu.reset_counters(); r.render(gs); gpu.sync()
+        out = ptamd.textures_to_numpy(r.textures); c = gpu.counters()
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+        for k in ("Position", "FlatNormal", "GeometricNormal", "NormalRoughness", "MotionVector", "LinearDepth"):
+            a, b = out[k], ref_gb[k]
+            if a.dtype.kind == "f":
+                a, b = a.view(np.uint32), b.view(np.uint32)
+            assert np.array_equal(a, b), (step, k)
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+        if step == 1:                                            # the bar moved between the frames: its pixels carry motion
+            mv = out["MotionVector"].view(np.float16)[..., :2].astype(np.float32)
+            assert np.abs(mv).max() > 1.0
+    assert np.array_equal(prev, scene.instance_data["ObjectToWorld"])
