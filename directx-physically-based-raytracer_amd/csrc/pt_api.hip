@@ -84,6 +84,7 @@ void pt_destroy(PtContext* ctx)
     }
     if (c.graphExec) hipGraphExecDestroy(c.graphExec);
     if (c.frameConstants) hipFree(c.frameConstants);
+    if (c.pixelAux) hipFree(c.pixelAux);
     if (c.queueCounts) hipFree(c.queueCounts);
     if (c.counters) hipFree(c.counters);
     for (auto e : c.evExtend) hipEventDestroy(e);
@@ -414,7 +415,9 @@ int pt_raytrace_render(PtContext* ctx, const PtTextures* tx)
     Context& c = ctx->c;
     API_ARG(&c, tx, "textures is NULL");
     if (!c.haveSettings) return fail(&c, PT_ERROR_NOT_READY, "call pt_raytrace_set_constants first");
-    API_ARG(&c, c.settings.Denoiser == 0 && !c.settings.IsDIEnabled, "only Denoiser::None with DI disabled is implemented");
+    API_ARG(&c, c.settings.Denoiser <= PT_DENOISER_NRD_RELAX, "unknown Denoiser value");
+    API_ARG(&c, !c.settings.IsDIEnabled, "IsDIEnabled needs the RTXDI passes, which are out of scope");
+    API_ARG(&c, !(c.settings.Denoiser >= PT_DENOISER_NRD_REBLUR) || (tx->Diffuse && tx->Specular), "NRD modes write Textures.Diffuse / Textures.Specular: not bound");
     API_ARG(&c, c.settings.SamplesPerPixel < 65536 && c.settings.Bounces < 32768, "SamplesPerPixel / Bounces out of range");
     API_ARG(&c, tx->Position && tx->FlatNormal && tx->GeometricNormal && tx->BaseColorMetalness && tx->NormalRoughness && tx->IOR
                  && tx->Transmission && tx->Radiance, "a G-buffer texture the path tracer reads is not bound (Raytracing::Textures)");

@@ -84,6 +84,7 @@ struct Context {
     void* blobDev = nullptr; BlobView blob{};        // compact traversal copy of TLAS + instances + every referenced BLAS
 
     PathQueue queue[2]{}; uint32_t queueCapacity = 0;
+    float2* pixelAux = nullptr; uint32_t pixelAuxCapacity = 0;   // denoiser modes: first-bounce hit distance | isDiffuse per pixel
     FrameConstants* frameConstants = nullptr;
     hipGraphExec_t graphExec = nullptr; std::string graphKey; bool disableGraphs = false;
     uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;

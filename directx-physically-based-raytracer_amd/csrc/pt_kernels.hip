@@ -305,7 +305,7 @@ __global__ void k_set_constants(FrameConstants v, FrameConstants* dst)
 // RNG state (all samples of a pixel draw from one stream, Raytracing.hlsl:108,191).
 
 // enqueue every primary-hit pixel as fresh (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
-__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, uint32_t segCap, uint32_t* countFresh)
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, float2* aux, uint32_t segCap, uint32_t* countFresh)
 {
     __shared__ uint32_t lds[8];
     const PtGraphicsSettings& gs = fc->gs;
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConsta
             q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
             q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng_init(x, y, gs.FrameIndex)));
             q.s2[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));            // sample 0, bounce 0
+            if (aux) aux[p] = make_float2(INFINITY, 1.0f);                               // hitDistance = inf, isDiffuse = true (:188-189)
         }
     }
 }
@@ -349,7 +350,7 @@ PT_DEV void store_path(const PathQueue& q, uint32_t i, const PathRegs& p)
 // weights, BSDF sample, throughput update, Russian roulette, luminance cut-off. Returns true when the path goes on
 // with the ray (newO, newD); false ends the sample. RNG draws happen exactly as in the reference, also on the last
 // iteration (bounce == Bounces), which samples but never traces (:213).
-PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit& h, const BSDFSample& bs, v3 emission, v3 rayDir, v3& newO, v3& newD)
+PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit& h, const BSDFSample& bs, v3 emission, v3 rayDir, v3& newO, v3& newD, int& lobe)
 {
     p.srad = p.srad + p.thr * emission;                          // :320
     const SurfaceVectors svec = surface_vectors(h.IsFrontFace, h.GeometricNormal, h.ShadingNormal);
@@ -357,7 +358,7 @@ PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit&
     float w[3]; bs.ComputeLobeWeights(svec, V, gs.ExtFlags, w);
     float rnd[4];
     rnd[0] = rng_float(p.rng); rnd[1] = rng_float(p.rng); rnd[2] = rng_float(p.rng); rnd[3] = rng_float(p.rng);   // GetFloat4, :330
-    v3 L; int lobe;
+    v3 L;
     if (!bs.Sample(svec, V, w, rnd, L, lobe)) return false;
     float pdf; v3 f;
     bs.EvaluateLobe(svec, L, V, w, lobe, gs.ExtFlags, pdf, f);
@@ -376,15 +377,30 @@ PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit&
     return true;
 }
 
-// sample ended: accumulate, start the next sample of the pixel or finish the pixel (Raytracing.hlsl:372-386)
-PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, PathRegs& p)
+// sample ended: accumulate, start the next sample of the pixel or finish the pixel (Raytracing.hlsl:372-413)
+PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const float2* aux, PathRegs& p)
 {
     p.rsum = p.rsum + p.srad;                                    // :372
     p.sample++;
     if (p.sample < gs.SamplesPerPixel) { p.thr = V3(1, 1, 1); p.srad = V3(0, 0, 0); p.bounce = 0; return true; }
     v3 out = V3(0, 0, 0);
-    if (finite3(p.rsum)) { const float ns = (float)gs.SamplesPerPixel; out = V3(p.rsum.x / ns, p.rsum.y / ns, p.rsum.z / ns); }
-    ((ushort4*)tx.Radiance)[p.pixel] = make_ushort4(f32_to_f16(out.x), f32_to_f16(out.y), f32_to_f16(out.z), 0);
+    if (finite3(p.rsum)) { const float ns = (float)gs.SamplesPerPixel; out = V3(p.rsum.x / ns, p.rsum.y / ns, p.rsum.z / ns); }   // :377
+    if (gs.Denoiser == PT_DENOISER_NRD_REBLUR || gs.Denoiser == PT_DENOISER_NRD_RELAX) {     // :400-413, direct terms are 0 (DI off)
+        const ushort4 rad = ((const ushort4*)tx.Radiance)[p.pixel];                          // primaryRadiance (G-buffer emission)
+        const v3 ind = V3(fmaxf(out.x - f16_to_f32(rad.x), 0.0f), fmaxf(out.y - f16_to_f32(rad.y), 0.0f), fmaxf(out.z - f16_to_f32(rad.z), 0.0f));
+        const float2 a = aux[p.pixel];
+        const ushort4 packed = make_ushort4(f32_to_f16(ind.x), f32_to_f16(ind.y), f32_to_f16(ind.z), f32_to_f16(a.x));
+        const ushort4 zero = make_ushort4(0, 0, 0, 0);
+        const bool isDiffuse = a.y != 0.0f;
+        if (tx.Diffuse) ((ushort4*)tx.Diffuse)[p.pixel] = isDiffuse ? packed : zero;
+        if (tx.Specular) ((ushort4*)tx.Specular)[p.pixel] = isDiffuse ? zero : packed;
+        return false;
+    }
+    if (gs.Denoiser == PT_DENOISER_DLSS_RAY_RECONSTRUCTION && tx.SpecularHitDistance) {      // :395-398
+        const float2 a = aux[p.pixel];
+        if (a.y == 0.0f && isfinite(a.x)) ((uint16_t*)tx.SpecularHitDistance)[p.pixel] = f32_to_f16(a.x);
+    }
+    ((ushort4*)tx.Radiance)[p.pixel] = make_ushort4(f32_to_f16(out.x), f32_to_f16(out.y), f32_to_f16(out.z), 0);     // :385 / :393
     if (tx.RadianceF32) ((float4*)tx.RadianceF32)[p.pixel] = make_float4(out.x, out.y, out.z, 0.0f);
     return false;
 }
@@ -392,7 +408,7 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, PathR
 // counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
-                                               PathQueue qin, PathQueue qout, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
+                                               PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
     __shared__ uint32_t lds[8];
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
@@ -411,7 +427,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
             const uint4 hr = qin.hit[i];
             const float4 rd = qin.r1[i];
             const v3 rayDir = V3(rd.x, rd.y, rd.z);
-            bool goes = false;
+            bool goes = false; int lobe = 0;
+            if (aux && p.sample == 0 && p.bounce == 1) aux[p.pixel].x = hr.x == ~0u ? INFINITY : rd.w;     // hitDistance, :235-239 (k_extend left t in r1.w)
             if (hr.x == ~0u) {                                   // :241-259
                 p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
             } else {                                             // :293-304
@@ -420,10 +437,10 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
                 const PtMaterial m = surface_material<TEXTURED>(sv, h);
                 BSDFSample bs;
                 bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
-                goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD);
+                goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD, lobe);
             }
             if (goes) toTraced = true;
-            else toFresh = end_sample(gs, tx, p);
+            else toFresh = end_sample(gs, tx, aux, p);
         }
         const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
         const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
@@ -464,8 +481,12 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
             const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
             BSDFSample bs;
             bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
-            if (scatter(gs, p, h, bs, emission, rayDir, newO, newD)) toTraced = true;
-            else toFresh = end_sample(gs, tx, p);
+            int lobe = 0;
+            const bool first = p.sample == 0;
+            if (scatter(gs, p, h, bs, emission, rayDir, newO, newD, lobe)) {
+                toTraced = true;
+                if (aux && first) aux[p.pixel].y = lobe == LOBE_DIFFUSE ? 1.0f : 0.0f;       // isDiffuse of the lobe sampled at bounce 0, :237
+            } else toFresh = end_sample(gs, tx, aux, p);
         }
         const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
         const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
@@ -510,7 +531,7 @@ constexpr int kStackLds2 = 16;
 constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u;
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
-template <bool STATS, bool LDS>
+template <bool STATS, bool LDS, bool WRITE_T = false>
 __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -536,6 +557,7 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
         const float4 o = q.r0[i], d = q.r1[i];
         const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+        if (WRITE_T) q.r1[i].w = h.t;                              // CommittedRayT for the denoiser hit-distance outputs
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 }
@@ -635,15 +657,16 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
     const uint32_t cstride = 2u * kSubQueues;                                  // traced + fresh counters per round
     hipError_t e;
     if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * cstride, c.stream)) != hipSuccess) return e;
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], segCap, &c.queueCounts[kSubQueues]);
+    float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, segCap, cin, cout);
-        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, segCap, cin, cout);
+        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
+        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
@@ -653,6 +676,9 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
             if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
             else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
+        } else if (aux) {                                              // denoiser modes need CommittedRayT
+            if (lds) k_extend2<false, true, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            else k_extend2<false, false, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
         } else if (lds) {
             if (stats) k_extend2<true, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
             else k_extend2<false, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
@@ -681,6 +707,12 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * 2u * kSubQueues);
     if (e != hipSuccess) return e;
     if (!c.frameConstants && (e = hipMalloc((void**)&c.frameConstants, sizeof(FrameConstants))) != hipSuccess) return e;
+    if (gs.Denoiser != PT_DENOISER_NONE && npix > c.pixelAuxCapacity) {
+        if (c.pixelAux) hipFree(c.pixelAux);
+        c.pixelAux = nullptr; c.pixelAuxCapacity = 0;
+        if ((e = hipMalloc((void**)&c.pixelAux, (size_t)npix * sizeof(float2))) != hipSuccess) return e;
+        c.pixelAuxCapacity = npix;
+    }
     FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
     k_set_constants<<<1, 192, 0, c.stream>>>(fc, c.frameConstants);
     const uint32_t grid = persistent_grid(c.device);
@@ -692,7 +724,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         std::string key;
         key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
         key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
-        key_add(key, c.frameConstants); key_add(key, c.stream);
+        key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser);
         if (key != c.graphKey || !c.graphExec) {
             if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }
             c.graphKey.clear();

@@ -114,6 +114,9 @@ GBUFFER_FORMATS = {
     "Radiance": ("<u2", 4),            # RGBA16F
 }
 GBUFFER_ORDER = list(GBUFFER_FORMATS.keys())
+# denoiser-facing outputs of the path tracer (Source/App.cpp:475-482)
+DENOISER_FORMATS = {"Diffuse": ("<u2", 4), "Specular": ("<u2", 4), "SpecularHitDistance": ("<u2", 1)}
+DENOISER_NONE, DENOISER_DLSS_RR, DENOISER_NRD_REBLUR, DENOISER_NRD_RELAX = 0, 1, 2, 3     # Source/Denoiser.ixx:8
 
 
 def default_material():

@@ -47,7 +47,7 @@ class InstanceDesc(C.Structure):
                 ("AccelerationStructure", C.c_uint64)]
 
 
-TEXTURE_NAMES = L.GBUFFER_ORDER + ["RadianceF32"]
+TEXTURE_NAMES = L.GBUFFER_ORDER + ["RadianceF32", "Diffuse", "Specular", "SpecularHitDistance"]
 
 
 class Textures(C.Structure):
@@ -303,7 +303,7 @@ class Scene:
         return self.ctx.handle        # the context owns the single TLAS
 
 
-def alloc_textures(width, local_rows_, device, with_f32=False):
+def alloc_textures(width, local_rows_, device, with_f32=False, with_denoiser_outputs=False):
     """The G-buffer textures of App::CreateWindowSizeDependentResources (Source/App.cpp:438-455) as
     linear CUDA tensors in the same DXGI formats."""
     torch = _torch()
@@ -313,6 +313,9 @@ def alloc_textures(width, local_rows_, device, with_f32=False):
         out[name] = torch.zeros((local_rows_, width, ch), dtype=tmap[dt], device=device)
     if with_f32:
         out["RadianceF32"] = torch.zeros((local_rows_, width, 4), dtype=torch.float32, device=device)
+    if with_denoiser_outputs:
+        for name, (dt, ch) in L.DENOISER_FORMATS.items():
+            out[name] = torch.zeros((local_rows_, width, ch), dtype=tmap[dt], device=device)
     return out
 
 
@@ -330,6 +333,8 @@ def textures_to_numpy(tex):
         a = t.detach().cpu().numpy()
         if name in L.GBUFFER_FORMATS:
             a = a.view(np.dtype(L.GBUFFER_FORMATS[name][0]))
+        elif name in L.DENOISER_FORMATS:
+            a = a.view(np.dtype(L.DENOISER_FORMATS[name][0]))
         out[name] = a
     return out
 
@@ -380,11 +385,11 @@ class Raytracing:
 class Renderer:
     """App::RenderScene for this path (Source/App.cpp:1157-1329): G-buffer pass, then the path tracer."""
 
-    def __init__(self, ctx, scene_gpu, width, height, with_f32=False):
+    def __init__(self, ctx, scene_gpu, width, height, with_f32=False, with_denoiser_outputs=False):
         self.ctx, self.scene, self.width, self.height = ctx, scene_gpu, width, height
         rank, world, band = getattr(ctx, "sharding", (0, 1, 16))
         self.local_rows = local_rows(height, rank, world, band)
-        self.textures = alloc_textures(width, self.local_rows, scene_gpu.device, with_f32)
+        self.textures = alloc_textures(width, self.local_rows, scene_gpu.device, with_f32, with_denoiser_outputs)
         self.gbuffer = GBufferGeneration(ctx)
         self.raytracing = Raytracing(ctx)
         d = scene_gpu.desc

@@ -102,11 +102,15 @@ typedef struct PtGraphicsSettings {       /* Raytracing::GraphicsSettings, Sourc
     uint32_t FrameIndex, Bounces, SamplesPerPixel;
     float ThroughputThreshold;            /* reference default 1e-3 */
     uint32_t IsRussianRouletteEnabled, IsShaderExecutionReorderingEnabled, IsDIEnabled;
-    uint32_t Denoiser;                    /* only 0 (None) is implemented */
+    uint32_t Denoiser;                    /* PtDenoiser: selects which outputs Raytracing writes (Raytracing.hlsl:379-413) */
     uint32_t ExtFlags;                    /* reference: first padding word. PT_EXT_* build-side switches */
     uint32_t _pad;
     uint32_t SHARC[8];                    /* out of scope, ignored */
 } PtGraphicsSettings;
+
+/* enum class Denoiser, Source/Denoiser.ixx:8. The denoisers themselves (NRD, DLSS-RR) are out of scope; these values only
+ * select the output packing the path tracer hands to them. */
+enum PtDenoiser { PT_DENOISER_NONE = 0, PT_DENOISER_DLSS_RAY_RECONSTRUCTION = 1, PT_DENOISER_NRD_REBLUR = 2, PT_DENOISER_NRD_RELAX = 3 };
 
 #define PT_EXT_LAMBERTIAN_ONLY 0x1u       /* BASELINE.json config C1: lobe weights {1,0,0}, DiffuseTerm = 1/pi */
 
@@ -143,6 +147,10 @@ typedef struct PtTextures {
     void* Transmission;        /* R8_UNORM             1 B */
     void* Radiance;            /* R16G16B16A16_FLOAT   8 B : G-buffer emission/environment in, path-traced radiance out */
     void* RadianceF32;         /* build-side extra, optional: R32G32B32A32_FLOAT copy of the value stored to Radiance */
+    /* denoiser-facing outputs of Raytracing::Textures (Source/Raytracing.ixx:55-58), written per Raytracing.hlsl:387-413 */
+    void* Diffuse;             /* R16G16B16A16_FLOAT   8 B : NRD: indirect diffuse radiance, hit distance in a */
+    void* Specular;            /* R16G16B16A16_FLOAT   8 B : NRD: indirect specular radiance, hit distance in a */
+    void* SpecularHitDistance; /* R16_FLOAT            2 B : DLSS-RR: first-bounce hit distance of specular pixels */
 } PtTextures;
 
 /* ------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ class HeapEntry(C.Structure):
 
 GB_NAMES = ["Position", "FlatNormal", "GeometricNormal", "LinearDepth", "NormalizedDepth", "MotionVector",
             "BaseColorMetalness", "DiffuseAlbedo", "SpecularAlbedo", "NormalRoughness", "IOR", "Transmission",
-            "Radiance", "RadianceF32"]
+            "Radiance", "RadianceF32", "Diffuse", "Specular", "SpecularHitDistance"]
 
 
 class GBufferTextures(C.Structure):
@@ -145,8 +145,9 @@ class OracleScene:
     @staticmethod
     def _textures(gb, extra_f32=None):
         t = GBufferTextures()
-        for n in GB_NAMES[:-1]:
-            setattr(t, n, gb[n].ctypes.data if n in gb and gb[n] is not None else None)
+        for n in GB_NAMES:
+            if n != "RadianceF32":
+                setattr(t, n, gb[n].ctypes.data if n in gb and gb[n] is not None else None)
         t.RadianceF32 = extra_f32.ctypes.data if extra_f32 is not None else None
         return t
 
@@ -173,6 +174,7 @@ def render(scene, settings, gbuffer_flags=0xFFFFFFFF & ~0xC0, accel_mode=0, thre
     Returns (gbuffer dict incl. final Radiance, rays_traced, radiance_f32 or None)."""
     W, H = int(settings["RenderSize"][0]), int(settings["RenderSize"][1])
     gb = {k: np.zeros((H, W, c), dt) for k, (dt, c) in layouts.GBUFFER_FORMATS.items()}
+    gb.update({k: np.zeros((H, W, c), dt) for k, (dt, c) in layouts.DENOISER_FORMATS.items()})
     consts = np.zeros((), layouts.GBUFFER_CONSTANTS)
     consts["RenderSize"] = (W, H); consts["Flags"] = gbuffer_flags
     osc = OracleScene(scene, accel_mode)

@@ -1421,6 +1421,7 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                 bsdf_init(&pb, ld3(bcm), bcm[3], nr[3], ior, tr, ph.IsFrontFace);
             }
             f3 radiance = F3(0, 0, 0);
+            int isDiffuse = 1; float hitDistance = INFINITY;                             /* :188-189 */
             const uint32_t spp = gs->SamplesPerPixel;
             for (uint32_t sample = 0; sample < spp; sample++) {                         /* :191 */
                 RayDesc ray = primaryRay;
@@ -1437,6 +1438,7 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                         isHit = cast_ray(s, &ray, &hit);
                         total_rays++;
                     }
+                    if (!sample && bounce == 1) { isDiffuse = lobe == LOBE_DIFFUSE; hitDistance = hit.Distance; }   /* :235-239 */
                     if (!isHit) {                                                       /* :241-259 */
                         f3 env = environment_light_color(s, sd, ray.Direction);
                         sampleRadiance = add3(sampleRadiance, mul3(throughput, env));
@@ -1473,7 +1475,17 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
             }
             if (finite3(radiance)) { float n = (float)spp; radiance = F3(radiance.x / n, radiance.y / n, radiance.z / n); }
             else radiance = F3(0, 0, 0);                                                /* :377 */
-            tx->Radiance[4 * pi + 0] = or_f32_to_f16(radiance.x);                       /* :385, RGBA16F store */
+            if (gs->Denoiser == 2 || gs->Denoiser == 3) {                               /* NRD ReBLUR / ReLAX, :400-413 (direct terms 0: DI off) */
+                f3 ind = F3(fmaxf(radiance.x - primaryRadiance.x, 0.0f), fmaxf(radiance.y - primaryRadiance.y, 0.0f), fmaxf(radiance.z - primaryRadiance.z, 0.0f));
+                uint16_t packed[4] = { or_f32_to_f16(ind.x), or_f32_to_f16(ind.y), or_f32_to_f16(ind.z), or_f32_to_f16(hitDistance) };
+                uint16_t zero[4] = { 0, 0, 0, 0 };
+                if (tx->Diffuse) memcpy(&tx->Diffuse[4 * pi], isDiffuse ? packed : zero, 8);
+                if (tx->Specular) memcpy(&tx->Specular[4 * pi], isDiffuse ? zero : packed, 8);
+                continue;
+            }
+            if (gs->Denoiser == 1 && !isDiffuse && isfinite(hitDistance) && tx->SpecularHitDistance)    /* DLSS-RR, :395-398 */
+                tx->SpecularHitDistance[pi] = or_f32_to_f16(hitDistance);
+            tx->Radiance[4 * pi + 0] = or_f32_to_f16(radiance.x);                       /* :385 / :393, RGBA16F store */
             tx->Radiance[4 * pi + 1] = or_f32_to_f16(radiance.y);
             tx->Radiance[4 * pi + 2] = or_f32_to_f16(radiance.z);
             tx->Radiance[4 * pi + 3] = 0;

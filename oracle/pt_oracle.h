@@ -134,6 +134,9 @@ typedef struct OrGBufferTextures {
     uint16_t* Radiance;            /* RGBA16F   8 B/px */
     float*    RadianceF32;         /* build-side extra (not a reference texture): RGBA32F copy of what
                                       or_raytrace_render stores to Radiance, before fp16 rounding; may be NULL */
+    uint16_t* Diffuse;             /* RGBA16F, NRD output (Raytracing.hlsl:400-413) */
+    uint16_t* Specular;            /* RGBA16F */
+    uint16_t* SpecularHitDistance; /* R16F, DLSS-RR output (:395-398) */
 } OrGBufferTextures;
 
 /* ---- acceleration-structure inputs (DXR-shaped) -------------------------- */

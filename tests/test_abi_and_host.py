@@ -35,7 +35,7 @@ def test_struct_sizes_match_reference_layouts(pkg, ptamd):
     assert L.CAMERA.fields["WorldToProjection"][1] == 416 and L.CAMERA.fields["Jitter"][1] == 88
     assert L.INSTANCE_DATA.fields["ObjectToWorld"][1] == 64
     assert C.sizeof(ptamd.GeometryDesc) == 40 and C.sizeof(ptamd.InstanceDesc) == 64
-    assert C.sizeof(ptamd.Textures) == 14 * 8 and C.sizeof(ptamd.Counters) == 64
+    assert C.sizeof(ptamd.Textures) == 17 * 8 and C.sizeof(ptamd.Counters) == 64
 
 
 def test_fails_loudly_without_gpu(ptamd):

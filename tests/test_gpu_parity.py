@@ -129,6 +129,36 @@ def test_textured_materials_alpha_test_and_environment_maps(gpu, ptamd, oracle, 
     assert (np.abs(ys - 0.6) < 1e-3).any() and (ys > 0.9).any()       # some pixels stop at the lattice (y=0.6), others pass to the ceiling / light
 
 
+def test_denoiser_facing_outputs(gpu, ptamd, oracle, pkg):
+    """Raytracing.hlsl:235-239,387-413: which lobe the first bounce of sample 0 took and how far it went, packed for
+    DLSS-RR (SpecularHitDistance) or NRD (Diffuse / Specular = indirect radiance + hit distance). The denoisers are out of
+    scope; the hand-off textures are not."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 128, 72
+    scene = S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True)
+    for denoiser in (L.DENOISER_DLSS_RR, L.DENOISER_NRD_REBLUR, L.DENOISER_NRD_RELAX):
+        gs = S.graphics_settings(W, H, spp=2, bounces=5, frame_index=4)
+        gs["Denoiser"] = denoiser
+        gpu.set_sharding(0, 1, 16)
+        g = ptamd.Scene(gpu, scene)
+        r = ptamd.Renderer(gpu, g, W, H, with_f32=True, with_denoiser_outputs=True)
+        gpu.reset_counters(); r.render(gs); gpu.sync()
+        out = ptamd.textures_to_numpy(r.textures); c = gpu.counters()
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        for k in ("Radiance", "Diffuse", "Specular", "SpecularHitDistance"):
+            assert np.array_equal(out[k], ref_gb[k]), (denoiser, k)
+        if denoiser == L.DENOISER_DLSS_RR:
+            d = out["SpecularHitDistance"].view(np.float16).astype(np.float32)
+            assert (d > 0).any() and np.isfinite(d).all()
+        else:
+            dif = out["Diffuse"].view(np.float16).astype(np.float32); spc = out["Specular"].view(np.float16).astype(np.float32)
+            assert (dif[..., :3].sum(-1) > 0).any() and (spc[..., :3].sum(-1) > 0).any()
+            assert not ((dif[..., :3].sum(-1) > 0) & (spc[..., :3].sum(-1) > 0)).any()        # a pixel is either diffuse or specular
+            # NRD modes leave Radiance as the G-buffer wrote it (emission / environment)
+            assert np.array_equal(out["Radiance"], ref_gb["Radiance"])
+
+
 def test_bounces_zero_and_misses(gpu, ptamd, oracle, pkg):
     S, L = pkg.scenes, pkg.layouts
     W, H = 128, 32
