@@ -370,10 +370,10 @@ int pt_deinterleave_bands(PtContext* ctx, void* dst_full, const void* gathered, 
 }
 
 // ---- operators ------------------------------------------------------------------------------
-static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv, FrameView& fv)
+static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv, FrameView& fv, bool needFrameInputs = true)
 {
     if (!c.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "no top-level acceleration structure: call pt_build_top_level first");
-    if (!c.haveCamera || !c.haveSceneData) return fail(&c, PT_ERROR_NOT_READY, "camera / scene data not set");
+    if (needFrameInputs && (!c.haveCamera || !c.haveSceneData)) return fail(&c, PT_ERROR_NOT_READY, "camera / scene data not set");
     if (!c.objects && c.tlas.instanceCount) return fail(&c, PT_ERROR_NOT_READY, "object data not set");
     int s = upload_heap(c);
     if (s != PT_OK) return s;
@@ -427,6 +427,29 @@ int pt_raytrace_render(PtContext* ctx, const PtTextures* tx)
     if (s != PT_OK) return s;
     if (c.settings.Bounces == 0) return PT_OK;          // reference: the pass is not dispatched, Source/App.cpp:1277-1279
     API_HIP(&c, launch_raytrace(c, sv, fv, *tx));
+    return PT_OK;
+}
+
+int pt_trace_visibility(PtContext* ctx, const PtRayDesc* device_rays, uint32_t count, float* device_visibility)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_ARG(&c, count == 0 || (device_rays && device_visibility), "ray / visibility buffer is NULL");
+    API_HIP(&c, hipSetDevice(c.device));
+    SceneView sv; FrameView fv; memset(&sv, 0, sizeof sv); memset(&fv, 0, sizeof fv);
+    int s = make_views(c, 1, 1, sv, fv, false);                    // only the scene half of the views is needed
+    if (s != PT_OK) return s;
+    API_HIP(&c, launch_visibility(c, sv, device_rays, count, device_visibility));
+    return PT_OK;
+}
+
+int pt_bsdf_evaluate(PtContext* ctx, const PtBsdfQuery* device_queries, uint32_t count, PtBsdfResult* device_results)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_ARG(&c, count == 0 || (device_queries && device_results), "query / result buffer is NULL");
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, launch_bsdf_evaluate(c.stream, (const float*)device_queries, count, (float*)device_results));
     return PT_OK;
 }
 

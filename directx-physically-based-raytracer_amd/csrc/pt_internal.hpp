@@ -11,8 +11,6 @@
 
 namespace pt {
 
-constexpr uint32_t kLeafTris = 4;            // triangles per BLAS leaf (count field is 3 bits: <= 8)
-
 struct Blas {
     BvhNode* nodes = nullptr;
     TriPacket* tris = nullptr;
@@ -110,6 +108,8 @@ hipError_t launch_skin(hipStream_t stream, const void* skeletal, const float* tr
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);
 hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx);
+hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
+hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 

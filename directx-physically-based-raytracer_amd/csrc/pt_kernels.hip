@@ -581,6 +581,54 @@ __global__ __launch_bounds__(256) void k_extend(AccelView av, AlphaContext ac, P
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 }
 
+static uint32_t persistent_grid(int device);
+
+// batch entry points for direct-lighting style consumers (RTXDI bridge shape), see include/ptamd.h
+__global__ __launch_bounds__(256) void k_visibility(AccelView av, AlphaContext ac, const float4* __restrict__ rays, uint32_t count, float4* __restrict__ out)
+{
+    __shared__ int ldsStack[kLdsStackDepth * 256];
+    int spill[kStackSize - kLdsStackDepth];
+    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float4 o = rays[2 * (size_t)i], d = rays[2 * (size_t)i + 1];
+        v3 vis;
+        const bool unoccluded = trace_visibility(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, vis);
+        out[i] = make_float4(vis.x, vis.y, vis.z, unoccluded ? 1.0f : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bsdf_evaluate(const float* __restrict__ q, uint32_t count, float* __restrict__ r)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float* a = q + 20 * (size_t)i;
+    BSDFSample b;
+    const bool front = a[7] != 0.0f;
+    b.Initialize(V3(a), a[3], a[4], a[5], a[6], front);
+    const SurfaceVectors sv = surface_vectors(front, V3(a + 8), V3(a + 11));
+    const v3 V = V3(a + 14), L = V3(a + 17);
+    float w[3]; b.ComputeLobeWeights(sv, V, 0, w);
+    float pdf; v3 dif, spc;
+    b.EvaluateAll(sv, L, V, w, pdf, dif, spc);
+    float* o = r + 8 * (size_t)i;
+    o[0] = dif.x; o[1] = dif.y; o[2] = dif.z; o[3] = spc.x; o[4] = spc.y; o[5] = spc.z; o[6] = pdf; o[7] = 0.0f;
+}
+
+hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out)
+{
+    if (!count) return hipSuccess;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    k_visibility<<<persistent_grid(c.device), 256, 0, c.stream>>>(sv.accel, ac, (const float4*)rays, count, (float4*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r)
+{
+    if (!count) return hipSuccess;
+    k_bsdf_evaluate<<<(count + 255) / 256, 256, 0, stream>>>(q, count, r);
+    return hipGetLastError();
+}
+
 __global__ void k_count_primary(DeviceCounters* counters, unsigned long long n) { atomicAdd(&counters->primaryRays, n); }
 
 // dst[y][x] <- gathered per-rank band buffers (PtSharding layout)

@@ -363,6 +363,22 @@ struct BSDFSample {                           // BxDF.hlsli:36-44
         return H;
     }
 
+    // all-lobe EvaluatePDF :247-264 and Evaluate :266-285 (the RTXDI-facing overloads), built from the single-lobe forms
+    PT_DEV void EvaluateAll(const SurfaceVectors& sv, v3 L, v3 V, const float w[3], float& pdf, v3& diffuse, v3& specular) const
+    {
+        const float tw = w[LOBE_TRANSMISSION];
+        pdf = 0.0f; diffuse = V3(0.0f, 0.0f, 0.0f); specular = V3(0.0f, 0.0f, 0.0f);
+        if (tw > 0.0f) { float p; v3 f; EvaluateLobe(sv, L, V, w, LOBE_TRANSMISSION, 0, p, f); pdf = p; specular = f; }
+        if (tw < 1.0f && dot(sv.FrontGeometricNormal, L) > 0.0f) {
+            float pd, ps; v3 fd, fs;
+            EvaluateLobe(sv, L, V, w, LOBE_DIFFUSE, 0, pd, fd);
+            EvaluateLobe(sv, L, V, w, LOBE_SPECULAR, 0, ps, fs);
+            pdf += pd + ps;
+            diffuse = fd;
+            specular = specular + fs;
+        }
+    }
+
     // single-lobe EvaluatePDF :287-299 and Evaluate :301-315, fused (they share H and the dots)
     PT_DEV void EvaluateLobe(const SurfaceVectors& sv, v3 L, v3 V, const float w[3], int lobe, uint32_t ext,
                              float& pdf, v3& f) const

@@ -122,6 +122,31 @@ PT_DEV bool is_opaque(const PtObjectData* od, const HeapEntry* heap, const float
     return a >= od->Material.AlphaCutoff;
 }
 
+// IsOpaque (direct-lighting overload with coloured visibility), ShadingHelpers.hlsli:117-159: true = the candidate blocks the ray
+PT_DEV bool is_opaque_visibility(const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc, v3& vis)
+{
+    PtMaterial m = od->Material;
+    const PtTextureMapInfo* ti = od->TextureMapInfoArray;
+    if ((m.BaseColor[0] > 0.0f || m.BaseColor[1] > 0.0f || m.BaseColor[2] > 0.0f || m.BaseColor[3] > 0.0f) && ti[TEX_BaseColor].Descriptor != ~0u) {
+        const f4 t = sample_map(heap, srgbLut, ti[TEX_BaseColor], tc);
+        m.BaseColor[0] *= t.x; m.BaseColor[1] *= t.y; m.BaseColor[2] *= t.z; m.BaseColor[3] *= t.w;
+    }
+    if (m.AlphaMode != 0) {
+        const bool ret = m.BaseColor[3] >= m.AlphaCutoff;
+        vis = vis * (ret ? 0.0f : 1.0f);
+        return ret;
+    }
+    if (m.Metallic > 0.0f) {
+        if (ti[TEX_MetallicRoughness].Descriptor != ~0u) m.Metallic *= sample_map(heap, srgbLut, ti[TEX_MetallicRoughness], tc).z;
+        else if (ti[TEX_Metallic].Descriptor != ~0u) m.Metallic *= sample_map(heap, srgbLut, ti[TEX_Metallic], tc).x;
+        if (m.Metallic == 1.0f) { vis = V3(0.0f, 0.0f, 0.0f); return true; }
+    }
+    if (m.Transmission > 0.0f && ti[TEX_Transmission].Descriptor != ~0u) m.Transmission *= sample_map(heap, srgbLut, ti[TEX_Transmission], tc).x;
+    vis = V3(vis.x * ((1.0f - m.Metallic) * m.BaseColor[0] * m.Transmission), vis.y * ((1.0f - m.Metallic) * m.BaseColor[1] * m.Transmission),
+             vis.z * ((1.0f - m.Metallic) * m.BaseColor[2] * m.Transmission));
+    return vis.x == 0.0f && vis.y == 0.0f && vis.z == 0.0f;
+}
+
 // EvaluateMaterial, ShadingHelpers.hlsli:161-235. N: shading normal (in/out), T: front tangent.
 PT_DEV PtMaterial evaluate_material(v3& N, v3 T, const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc)
 {

@@ -50,6 +50,12 @@ struct TraceStats { uint32_t nodes, tris; };
 constexpr int kEntryDone = 0x7FFFFFFF;
 constexpr int kEntryRestore = 0x7FFFFFFE;
 constexpr int kStackSize = 96;
+constexpr uint32_t kLeafTris = 4;            // triangles per BLAS leaf (count field is 3 bits: <= 8)
+
+// A tree of one leaf has no internal node worth a visit (its root node would list the same leaf twice): traversal
+// starts at the leaf itself. BLAS leaf 0 covers packets [0, triCount); the only TLAS leaf is instance 0.
+PT_DEV int blas_root_entry(uint32_t triCount) { return triCount <= kLeafTris ? ~(int)(triCount - 1u) : 0; }   // triCount >= 1
+PT_DEV int tlas_root_entry(uint32_t instCount) { return instCount == 1u ? ~0 : 0; }                            // instCount >= 1
 
 struct RaySetup { int kx, ky, kz; float Sx, Sy, Sz; };
 
@@ -216,7 +222,7 @@ PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d
 
     stack.sp = 0;
     stack.push(kEntryDone);
-    int cur = 0;
+    int cur = tlas_root_entry(av.instanceCount);
     while (true) {
         // ---- descend through internal nodes
         while (cur >= 0 && cur < kEntryRestore) {
@@ -244,7 +250,7 @@ PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d
         const uint32_t x = (uint32_t)~cur;
         if (!bottom) {
             const InstanceRecord* ir = &av.instances[x];
-            if (ir->mask & 0xFFu) {
+            if ((ir->mask & 0xFFu) && ir->triCount) {
                 const float* W = ir->worldToObject;
                 ro = V3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3],
                         W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7],
@@ -256,7 +262,7 @@ PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d
                 rs = ray_setup(rd);
                 nodes = ir->nodes; tris = ir->tris; curInst = x; bottom = true;
                 stack.push(kEntryRestore);
-                cur = 0;
+                cur = blas_root_entry(ir->triCount);
                 continue;
             }
         } else {
@@ -273,6 +279,74 @@ PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;
+}
+
+// TraceRay<RAY_FLAG_FORCE_NON_OPAQUE | RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH> (RaytracingHelpers.hlsli:7-55 with the
+// coloured-visibility IsOpaque; the shape RTXDIAppBridge.hlsli:418-439 uses for shadow rays). Every triangle inside
+// (tmin, tmax) is a candidate; a blocking one ends the search. Returns true when nothing was committed.
+template <typename STACK>
+PT_DEV bool trace_visibility(const AccelView& av, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax, STACK& stack, v3& vis)
+{
+    vis = V3(1.0f, 1.0f, 1.0f);
+    if (av.instanceCount == 0) return true;
+    v3 ro = o, rd = d;
+    v3 idir = safe_inv(rd), ood = ro * idir;
+    RaySetup rs; rs.kx = rs.ky = rs.kz = 0; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    const BvhNode* nodes = av.tlasNodes;
+    const TriPacket* tris = nullptr;
+    uint32_t curInst = ~0u;
+    bool bottom = false;
+    stack.sp = 0;
+    stack.push(kEntryDone);
+    int cur = tlas_root_entry(av.instanceCount);
+    while (true) {
+        while (cur >= 0 && cur < kEntryRestore) {
+            const BvhNode n = nodes[cur];
+            bool h0, h1; float t0, t1;
+            node_test(n, idir, ood, tmin, tmax, h0, h1, t0, t1);
+            if (h0 && h1) { stack.push(n.child.y); cur = n.child.x; }
+            else if (h0) cur = n.child.x;
+            else if (h1) cur = n.child.y;
+            else cur = stack.pop();
+        }
+        if (cur == kEntryDone) break;
+        if (cur == kEntryRestore) {
+            ro = o; rd = d; idir = safe_inv(rd); ood = ro * idir;
+            nodes = av.tlasNodes; bottom = false;
+            cur = stack.pop();
+            continue;
+        }
+        const uint32_t x = (uint32_t)~cur;
+        if (!bottom) {
+            const InstanceRecord* ir = &av.instances[x];
+            if ((ir->mask & 0xFFu) && ir->triCount) {
+                const float* W = ir->worldToObject;
+                ro = V3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3], W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7], W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
+                rd = V3(W[0] * d.x + W[1] * d.y + W[2]  * d.z, W[4] * d.x + W[5] * d.y + W[6]  * d.z, W[8] * d.x + W[9] * d.y + W[10] * d.z);
+                idir = safe_inv(rd); ood = ro * idir;
+                rs = ray_setup(rd);
+                nodes = ir->nodes; tris = ir->tris; curInst = x; bottom = true;
+                stack.push(kEntryRestore);
+                cur = blas_root_entry(ir->triCount);
+                continue;
+            }
+        } else {
+            const uint32_t first = x >> 3, count = (x & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const TriPacket tp = tris[first + i];
+                float t, u, v;
+                if (!tri_test(rs, ro, V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), t, u, v)) continue;
+                if (!(t > tmin && t < tmax)) continue;
+                const uint32_t geom = __float_as_uint(tp.a.w), prim = __float_as_uint(tp.b.w);
+                const PtObjectData* od = &ac.objects[ac.instances[curInst].instanceID + geom];
+                TexCoords tc;
+                get_texture_coordinates(od, ac.heap, prim, u, v, tc);
+                if (is_opaque_visibility(od, ac.heap, ac.srgbLut, tc, vis)) return false;
+            }
+        }
+        cur = stack.pop();
+    }
+    return true;
 }
 
 // Debug / validation traversal (PT_DEBUG_BRUTE_FORCE): every triangle of every instance, no BVH.

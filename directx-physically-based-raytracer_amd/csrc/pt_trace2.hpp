@@ -74,7 +74,7 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
     uint32_t* cand = ldsCand + threadIdx.x;
 
     const v3 idir = safe_inv(d), ood = o * idir;
-    int cur = 0;
+    int cur = tlas_root_entry(bv.instCount);
     bool tlasDone = false;
     while (true) {
         // ---------------- phase A: TLAS walk, collect candidates
@@ -109,7 +109,8 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
             const uint32_t ia = bv.instOff16 + x * kInst16;
             const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);          // boxLo|nodeBase, boxHi|triBase
             const f4v mk = blob.ld(ia + 5);                                  // mask, triCount, -, -
-            if (!(__float_as_uint(mk.x) & 0xFFu)) continue;
+            const uint32_t ntri = __float_as_uint(mk.y);
+            if (!(__float_as_uint(mk.x) & 0xFFu) || ntri == 0u) continue;
             {   // late cull against the current best hit
                 const float lx = __builtin_fmaf(b0.x, idir.x, -ood.x), hx = __builtin_fmaf(b1.x, idir.x, -ood.x);
                 const float ly = __builtin_fmaf(b0.y, idir.y, -ood.y), hy = __builtin_fmaf(b1.y, idir.y, -ood.y);
@@ -130,7 +131,7 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
             const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
             const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
             stack.push(kEntryRestore);
-            int c = 0;
+            int c = blas_root_entry(ntri);
             while (true) {
                 while (c >= 0 && c < kEntryRestore) {
                     const uint32_t a = nodeBase + (uint32_t)c * kNode16;

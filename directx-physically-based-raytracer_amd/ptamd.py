@@ -23,7 +23,7 @@ EXPORTS = [
     "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
-    "pt_raytrace_set_constants", "pt_raytrace_render", "pt_reset_counters", "pt_get_counters",
+    "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
     "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_enable_kernel_timing", "pt_get_kernel_timing",
 ]
 
@@ -105,6 +105,8 @@ def load_library():
         lib.pt_deinterleave_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_uint32]
         lib.pt_gbuffer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pt_trace_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.pt_bsdf_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.pt_reset_counters.argtypes = [C.c_void_p]
         lib.pt_set_debug_flags.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_debug_read_mismatch.argtypes = [C.c_void_p, C.c_void_p]

@@ -277,6 +277,25 @@ int  pt_gbuffer_render(PtContext* ctx, const PtGBufferConstants* constants, cons
 int  pt_raytrace_set_constants(PtContext* ctx, const PtGraphicsSettings* settings);
 int  pt_raytrace_render(PtContext* ctx, const PtTextures* textures);
 
+/* ------------------------------------------------------------------------------------------
+ * building blocks the reference's direct-lighting bridge calls on the same data
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PtRayDesc { float Origin[3]; float TMin; float Direction[3]; float TMax; } PtRayDesc;   /* HLSL RayDesc, 32 B */
+/* Shadow rays: TraceRay<RAY_FLAG_FORCE_NON_OPAQUE | RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH>(q, ray, RAY_FLAG_NONE, ~0u)
+ * with the coloured-visibility IsOpaque (Shaders/RaytracingHelpers.hlsli:7-55, Shaders/ShadingHelpers.hlsli:117-159), as used by
+ * GetFinalVisibility / GetConservativeVisibility (Shaders/RTXDIAppBridge.hlsli:426-439).
+ * device_visibility: 4 floats per ray = visibility.rgb, then 1 if nothing was committed (unoccluded) else 0. */
+int  pt_trace_visibility(PtContext* ctx, const PtRayDesc* device_rays, uint32_t count, float* device_visibility);
+
+/* BSDFSample::Evaluate(surfaceVectors, L, V, lobeWeights, diffuse, specular) + EvaluatePDF(...), the all-lobe overloads
+ * (Shaders/BxDF.hlsli:247-285) after Initialize + ComputeLobeWeights, batched. */
+typedef struct PtBsdfQuery {
+    float BaseColor[3], Metallic, Roughness, IOR, Transmission, IsFrontFace;     /* IsFrontFace: 0 or 1 */
+    float GeometricNormal[3], ShadingNormal[3], V[3], L[3];
+} PtBsdfQuery;                            /* 80 B */
+typedef struct PtBsdfResult { float Diffuse[3], Specular[3], PDF, _pad; } PtBsdfResult;   /* 32 B */
+int  pt_bsdf_evaluate(PtContext* ctx, const PtBsdfQuery* device_queries, uint32_t count, PtBsdfResult* device_results);
+
 /* Measurement (no reference counterpart). Counters cover the work enqueued since the last reset;
  * reading them synchronises the stream. */
 typedef struct PtCounters {

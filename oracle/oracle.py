@@ -79,6 +79,8 @@ def lib():
         L.or_env_term_rtg.argtypes = [fp, C.c_float, C.c_float, fp]
         L.or_safe_spawn.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, fp]
         L.or_invert_3x4.argtypes = [fp, fp]
+        L.or_bsdf_evaluate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.or_trace_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.or_skin_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.or_texture_sample.argtypes = [C.c_void_p, C.c_float, C.c_float, fp]
         L.or_cube_sample.argtypes = [C.c_void_p, fp, fp]

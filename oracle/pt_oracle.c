@@ -501,6 +501,31 @@ static f3 bsdf_eval_lobe(const BSDFSample* b, const SurfaceVectors* sv, f3 L, f3
     return zero;
 }
 
+/* all-lobe EvaluatePDF :247-264 and Evaluate :266-285 */
+void or_bsdf_evaluate(const float* q, uint32_t count, float* r)
+{
+    for (uint32_t i = 0; i < count; i++, q += 20, r += 8) {
+        BSDFSample b;
+        int front = q[7] != 0.0f;
+        bsdf_init(&b, ld3(q), q[3], q[4], q[5], q[6], front);
+        SurfaceVectors sv = surface_vectors(front, ld3(q + 8), ld3(q + 11));
+        f3 V = ld3(q + 14), L = ld3(q + 17);
+        float w[3]; compute_lobe_weights(&b, &sv, V, 0, w);
+        const float tw = w[LOBE_TRANSMISSION];
+        float pdf = 0.0f; f3 dif = F3(0, 0, 0), spc = F3(0, 0, 0);
+        if (tw > 0.0f) {
+            pdf = bsdf_pdf_lobe(&b, &sv, L, V, w, LOBE_TRANSMISSION);
+            spc = bsdf_eval_lobe(&b, &sv, L, V, w, LOBE_TRANSMISSION, 0);
+        }
+        if (tw < 1.0f && dot3(sv.FrontGeometricNormal, L) > 0.0f) {
+            pdf += bsdf_pdf_lobe(&b, &sv, L, V, w, LOBE_DIFFUSE) + bsdf_pdf_lobe(&b, &sv, L, V, w, LOBE_SPECULAR);
+            dif = bsdf_eval_lobe(&b, &sv, L, V, w, LOBE_DIFFUSE, 0);
+            spc = add3(spc, bsdf_eval_lobe(&b, &sv, L, V, w, LOBE_SPECULAR, 0));
+        }
+        r[0] = dif.x; r[1] = dif.y; r[2] = dif.z; r[3] = spc.x; r[4] = spc.y; r[5] = spc.z; r[6] = pdf; r[7] = 0.0f;
+    }
+}
+
 int or_bsdf_sample(const float mat[7], int front_face, const float Ng[3], const float Ns[3],
                    const float Vv[3], const float rnd[4], uint32_t ext_flags,
                    float Lout[3], int* lobe, float* pdf, float f[3], float weights[3])
@@ -1103,6 +1128,61 @@ static int candidate_is_opaque(const OrScene* s, uint32_t inst, uint32_t geom, u
     float uv[2][2];
     get_texture_coordinates(od, s->heap, prim, u, v, uv);
     return is_opaque(od, s->heap, uv);
+}
+
+/* ======================================================================== */
+/* visibility rays: TraceRay<FORCE_NON_OPAQUE | ACCEPT_FIRST_HIT>, IsOpaque (direct lighting overload)          */
+/* ======================================================================== */
+/* ShadingHelpers.hlsli:117-159: returns 1 when the candidate blocks the ray (commit + end search) */
+static int is_opaque_visibility(const OrObjectData* od, const OrHeapEntry* heap, const float uv[2][2], float vis[3])
+{
+    OrMaterial m = od->Material;
+    const OrTextureMapInfo* ti = od->TextureMapInfoArray;
+    float t[4];
+    evaluate_base_color(m.BaseColor, heap, &ti[TEX_BaseColor], uv);
+    if (m.AlphaMode != 0) {
+        int ret = m.BaseColor[3] >= m.AlphaCutoff;
+        for (int c = 0; c < 3; c++) vis[c] *= ret ? 0.0f : 1.0f;
+        return ret;
+    }
+    if (m.Metallic > 0.0f) {
+        if (ti[TEX_MetallicRoughness].Descriptor != ~0u) { sample_map(heap, &ti[TEX_MetallicRoughness], uv, t); m.Metallic *= t[2]; }
+        else if (ti[TEX_Metallic].Descriptor != ~0u) { sample_map(heap, &ti[TEX_Metallic], uv, t); m.Metallic *= t[0]; }
+        if (m.Metallic == 1.0f) { vis[0] = vis[1] = vis[2] = 0.0f; return 1; }
+    }
+    if (m.Transmission > 0.0f && ti[TEX_Transmission].Descriptor != ~0u) { sample_map(heap, &ti[TEX_Transmission], uv, t); m.Transmission *= t[0]; }
+    for (int c = 0; c < 3; c++) vis[c] *= (1.0f - m.Metallic) * m.BaseColor[c] * m.Transmission;
+    return vis[0] == 0.0f && vis[1] == 0.0f && vis[2] == 0.0f;
+}
+
+void or_trace_visibility(const OrScene* s, const float* rays, uint32_t count, float* out)
+{
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t ii = 0; ii < (int64_t)count; ii++) {
+        const float* r = rays + 8 * ii;
+        f3 o = ld3(r), d = ld3(r + 4); float tmin = r[3], tmax = r[7];
+        float vis[3] = { 1.0f, 1.0f, 1.0f }; int committed = 0;
+        /* every triangle of every instance (any-hit order is undefined in DXR; brute force, ascending ids) */
+        for (uint32_t in = 0; in < s->n_inst && !committed; in++) {
+            const OrInstanceDesc* I = &s->inst[in];
+            if (!(I->InstanceMask & 0xFFu)) continue;
+            const float* W = &s->w2o[12 * in];
+            f3 oo = F3(W[0] * o.x + W[1] * o.y + W[2] * o.z + W[3], W[4] * o.x + W[5] * o.y + W[6] * o.z + W[7], W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
+            f3 od = F3(W[0] * d.x + W[1] * d.y + W[2] * d.z, W[4] * d.x + W[5] * d.y + W[6] * d.z, W[8] * d.x + W[9] * d.y + W[10] * d.z);
+            RayObj ro; ray_setup(&ro, oo, od);
+            const Blas* B = &s->blas[I->Blas];
+            for (uint32_t k = 0; k < B->n_tris && !committed; k++) {
+                float t, u, v;
+                if (!tri_test(&ro, B->tris[k].v0, B->tris[k].v1, B->tris[k].v2, &t, &u, &v)) continue;
+                if (!(t > tmin && t < tmax)) continue;
+                const OrObjectData* odt = &s->objects[I->InstanceID + B->tris[k].geom];
+                float uv[2][2];
+                get_texture_coordinates(odt, s->heap, B->tris[k].prim, u, v, uv);
+                if (is_opaque_visibility(odt, s->heap, uv, vis)) committed = 1;
+            }
+        }
+        out[4 * ii] = vis[0]; out[4 * ii + 1] = vis[1]; out[4 * ii + 2] = vis[2]; out[4 * ii + 3] = committed ? 0.0f : 1.0f;
+    }
 }
 
 /* ======================================================================== */

@@ -214,6 +214,14 @@ void     or_env_term_rtg(const float f0[3], float NoV, float roughness, float ou
 void     or_safe_spawn(const float v[9], const float bary[2], const float o2w[12], const float w2o[12],
                        float objPos[3], float wldPos[3], float objN[3], float wldN[3], float* offset);
 void     or_invert_3x4(const float m[12], float out[12]);
+/* BSDFSample::Evaluate / EvaluatePDF, all-lobe overloads (BxDF.hlsli:247-285; consumer: RTXDIAppBridge.hlsli:249-263).
+ * q: 20 floats per query = base.rgb metallic roughness ior transmission frontFace(0/1) Ng.xyz Ns.xyz V.xyz L.xyz
+ * r:  8 floats per query = diffuse.rgb specular.rgb pdf 0 */
+void     or_bsdf_evaluate(const float* q, uint32_t count, float* r);
+/* TraceRay<FORCE_NON_OPAQUE | ACCEPT_FIRST_HIT_AND_END_SEARCH> with the coloured-visibility IsOpaque overload
+ * (RaytracingHelpers.hlsli:7-55, ShadingHelpers.hlsli:117-159, RTXDIAppBridge.hlsli:418-439).
+ * rays: 8 floats per ray = origin.xyz tmin dir.xyz tmax; out: 4 floats = visibility.rgb, 1 if nothing was committed else 0 */
+void     or_trace_visibility(const OrScene* scene, const float* rays, uint32_t count, float* out);
 /* SkeletalMeshSkinning.hlsl:28-62. skeletal: VertexPositionNormalTangentSkin (48 B: pos f32x3, normal i16x3, tangent i16x3,
  * joints u16x4, weights f32x4); transforms: row-major 3x4 per joint; vertices: 32-B vertex (in/out); motion: half4 per vertex */
 void     or_skin_mesh(const void* skeletal, const float* transforms, void* vertices, uint16_t* motion, uint32_t count);
