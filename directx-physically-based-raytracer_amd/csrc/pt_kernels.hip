@@ -227,6 +227,15 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
             bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
             if (tx.BaseColorMetalness)
                 ((uchar4*)tx.BaseColorMetalness)[pi] = make_uchar4(f32_to_unorm8(bs.BaseColor.x), f32_to_unorm8(bs.BaseColor.y), f32_to_unorm8(bs.BaseColor.z), f32_to_unorm8(bs.Metallic));
+            if (flags & PT_GB_Albedo) {        // EstimateDemodulationFactors (BxDF.hlsli:317-320) = NRD_MaterialFactors, see DESIGN.md [NRD spec]
+                const float NoV = fabsf(dot(h.ShadingNormal, -ray.d));
+                const v3 Fe = ml_env_term_rtg(bs.F0, NoV, bs.Roughness);
+                if ((flags & PT_GB_DiffuseAlbedo) && tx.DiffuseAlbedo)
+                    ((ushort4*)tx.DiffuseAlbedo)[pi] = make_ushort4(f32_to_f16((1.0f - Fe.x) * bs.Albedo.x * 0.99f + 0.01f), f32_to_f16((1.0f - Fe.y) * bs.Albedo.y * 0.99f + 0.01f),
+                                                                     f32_to_f16((1.0f - Fe.z) * bs.Albedo.z * 0.99f + 0.01f), 0);
+                if ((flags & PT_GB_SpecularAlbedo) && tx.SpecularAlbedo)
+                    ((ushort4*)tx.SpecularAlbedo)[pi] = make_ushort4(f32_to_f16(Fe.x * 0.99f + 0.01f), f32_to_f16(Fe.y * 0.99f + 0.01f), f32_to_f16(Fe.z * 0.99f + 0.01f), 0);
+            }
             if (tx.IOR) ((uint16_t*)tx.IOR)[pi] = f32_to_f16(m.IOR);
             if (bs.Metallic < 1.0f && tx.Transmission) ((uint8_t*)tx.Transmission)[pi] = f32_to_unorm8(bs.Transmission);
             if ((flags & PT_GB_Radiance) && tx.Radiance) {

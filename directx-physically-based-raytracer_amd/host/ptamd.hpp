@@ -5,6 +5,7 @@
 //     struct GBufferGeneration   Source/GBufferGeneration.ixx:27-122
 //     struct Raytracing          Source/Raytracing.ixx:29-250      (DEFAULT permutation; SHARC overload absent)
 //     BuildTopLevelAccelerationStructure / CreateGeometryDesc       Source/RaytracingHelpers.ixx:28-105
+//     struct SkeletalMeshSkinning Source/SkeletalMeshSkinning.ixx:20-66
 // Error behaviour: a failing status becomes the exception type the reference throws at the same place
 // (std::invalid_argument for argument checks, std::system_error otherwise: Source/ErrorHelpers.ixx:16-32).
 // Header-only, plain C++20 (std::span), no HIP headers needed by the including translation unit.
@@ -81,7 +82,70 @@ inline uint64_t BuildBottomLevelAccelerationStructure(CommandList& commandList, 
     return id;
 }
 
+// CommandList::UpdateAccelerationStructures for one bottom-level input (PERFORM_UPDATE after skinning), Source/CommandList.ixx:235-241
+inline void UpdateBottomLevelAccelerationStructure(CommandList& commandList, uint64_t id, std::span<const PtGeometryDesc> geometryDescs, uint32_t flags)
+{
+    ThrowIfFailed(commandList.Context, pt_update_bottom_level(commandList.Context, id, geometryDescs.data(), (uint32_t)geometryDescs.size(), flags));
+}
+
+// RTXMU RemoveAccelerationStructures in ~Scene / CollectGarbage, Source/Scene.ixx:108-123
+inline void ReleaseBottomLevelAccelerationStructure(CommandList& commandList, uint64_t id)
+{
+    ThrowIfFailed(commandList.Context, pt_release_bottom_level(commandList.Context, id));
+}
+
 } // namespace RaytracingHelpers
+
+// The shader-visible descriptor heap (DeviceContext::ResourceDescriptorHeap): slots that ObjectData / SceneData index.
+struct DescriptorHeap {
+    explicit DescriptorHeap(CommandList& commandList, uint32_t capacity) : m_context(commandList.Context)
+    {
+        ThrowIfFailed(m_context, pt_heap_resize(m_context, capacity));
+    }
+    // GPUBuffer::CreateSRV(Raw|Structured|Typed), Source/GPUBuffer.ixx: vertex / index / motion-vector buffers (App.cpp:1046-1050)
+    void SetBuffer(uint32_t descriptor, const GPUBuffer& buffer)
+    {
+        ThrowIfFailed(m_context, pt_heap_set_buffer(m_context, descriptor, buffer.DevicePointer, buffer.Capacity * buffer.Stride, buffer.Stride));
+    }
+    // Texture::CreateSRV for a material map or the environment map (App.cpp:1021-1024,1052-1063); mip 0 texels, cube = 6 faces
+    void SetTexture(uint32_t descriptor, const void* texels, uint32_t width, uint32_t height, PtFormat format, bool isCubeMap = false)
+    {
+        ThrowIfFailed(m_context, pt_heap_set_texture(m_context, descriptor, texels, width, height, (uint32_t)format, isCubeMap ? 1u : 0u));
+    }
+private:
+    PtContext* m_context;
+};
+
+// struct SkeletalMeshSkinning, Source/SkeletalMeshSkinning.ixx:20-66 (Prepare has nothing to bind here)
+struct SkeletalMeshSkinning {
+    struct { const GPUBuffer* SkeletalVertices; const GPUBuffer* SkeletalTransforms; const GPUBuffer* Vertices; const GPUBuffer* MotionVectors; } GPUBuffers{};
+
+    explicit SkeletalMeshSkinning(CommandList&) {}
+    void Prepare(CommandList&) {}
+    void Process(CommandList& commandList)                  // :43-65, vertexCount = Vertices->GetCapacity()
+    {
+        if (!GPUBuffers.SkeletalVertices || !GPUBuffers.SkeletalTransforms || !GPUBuffers.Vertices || !GPUBuffers.MotionVectors)
+            throw std::invalid_argument("SkeletalMeshSkinning::GPUBuffers not set");
+        ThrowIfFailed(commandList.Context, pt_skin_mesh(commandList.Context, GPUBuffers.SkeletalVertices->DevicePointer,
+                                                        (const float*)GPUBuffers.SkeletalTransforms->DevicePointer,
+                                                        const_cast<void*>(GPUBuffers.Vertices->DevicePointer),
+                                                        const_cast<void*>(GPUBuffers.MotionVectors->DevicePointer),
+                                                        (uint32_t)GPUBuffers.Vertices->Capacity));
+    }
+};
+
+// The two calls the reference's direct-lighting bridge makes on the same scene data (Shaders/RTXDIAppBridge.hlsli:418-439,
+// Shaders/BxDF.hlsli:247-285), batched over device arrays.
+namespace DirectLighting {
+inline void TraceVisibility(CommandList& commandList, const PtRayDesc* deviceRays, uint32_t count, float* deviceVisibility)
+{
+    ThrowIfFailed(commandList.Context, pt_trace_visibility(commandList.Context, deviceRays, count, deviceVisibility));
+}
+inline void EvaluateBSDF(CommandList& commandList, const PtBsdfQuery* deviceQueries, uint32_t count, PtBsdfResult* deviceResults)
+{
+    ThrowIfFailed(commandList.Context, pt_bsdf_evaluate(commandList.Context, deviceQueries, count, deviceResults));
+}
+} // namespace DirectLighting
 
 struct GBufferGeneration {
     struct Flags {                                          // Source/GBufferGeneration.ixx:28-44
@@ -129,7 +193,7 @@ struct Raytracing {
     };
 
     struct { const PtSceneData* SceneData; const PtCamera* Camera; const PtObjectData* ObjectData; uint32_t ObjectCount; } GPUBuffers{};
-    PtTextures Textures{};                                  // Position .. Radiance (+ Diffuse/Specular slots unused: denoiser only)
+    PtTextures Textures{};                                  // Position .. Radiance; Diffuse / Specular / SpecularHitDistance when GraphicsSettings.Denoiser != None
 
     explicit Raytracing(CommandList& commandList) : m_context(commandList.Context) {}
 

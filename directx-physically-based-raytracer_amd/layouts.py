@@ -106,8 +106,8 @@ GBUFFER_FORMATS = {
     "NormalizedDepth": ("<f4", 1),     # R32F
     "MotionVector": ("<u2", 4),        # RGBA16F (raw half bits)
     "BaseColorMetalness": ("u1", 4),   # RGBA8_UNORM
-    "DiffuseAlbedo": ("<u2", 4),       # unused on this path
-    "SpecularAlbedo": ("<u2", 4),      # unused on this path
+    "DiffuseAlbedo": ("<u2", 4),       # RGBA16F, written when a denoiser is selected
+    "SpecularAlbedo": ("<u2", 4),      # RGBA16F, written when a denoiser is selected
     "NormalRoughness": ("<i2", 4),     # RGBA16_SNORM
     "IOR": ("<u2", 1),                 # R16F
     "Transmission": ("u1", 1),         # R8_UNORM

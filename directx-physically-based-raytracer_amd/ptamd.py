@@ -405,6 +405,8 @@ class Renderer:
 
     def render(self, settings):
         tlas = self.scene.GetTopLevelAccelerationStructure()
+        denoiser = int(np.array(settings).reshape(())["Denoiser"])
+        self.constants["Flags"] = 0xFFFFFFFF if denoiser != L.DENOISER_NONE else L.GBufferFlags.DefaultNoDenoiser   # App.cpp:1223
         self.gbuffer.Render(tlas, self.constants)
         if int(np.array(settings).reshape(())["Bounces"]) > 0:            # App.cpp:1277
             self.raytracing.SetConstants(settings)

@@ -131,7 +131,8 @@ enum PtGBufferFlags {                     /* Source/GBufferGeneration.ixx:28-44 
  * framebuffer (see PtSharding), in the reference's DXGI formats (Source/App.cpp:438-455).
  * Same member order as GBufferGeneration::Textures (Source/GBufferGeneration.ixx:53-68);
  * Raytracing::Textures (Source/Raytracing.ixx:46-59) is the subset the path tracer reads plus
- * Radiance. NULL = not bound. DiffuseAlbedo / SpecularAlbedo are denoiser-only and never written. */
+ * Radiance. NULL = not bound. DiffuseAlbedo / SpecularAlbedo (GBufferGeneration.hlsl:171-186) are written only when
+ * their flag is set, which the reference does when a denoiser is selected (Source/App.cpp:1223). */
 typedef struct PtTextures {
     void* Position;            /* R32G32B32A32_FLOAT  16 B : xyz world position, w = spawn offset; all +inf on miss */
     void* FlatNormal;          /* R16G16_SNORM         4 B : signed octahedral */
@@ -140,8 +141,8 @@ typedef struct PtTextures {
     void* NormalizedDepth;     /* R32_FLOAT            4 B */
     void* MotionVector;        /* R16G16B16A16_FLOAT   8 B */
     void* BaseColorMetalness;  /* R8G8B8A8_UNORM       4 B */
-    void* DiffuseAlbedo;       /* unused */
-    void* SpecularAlbedo;      /* unused */
+    void* DiffuseAlbedo;       /* R16G16B16A16_FLOAT   8 B  NRD_MaterialFactors diffuse (only with PT_GB_DiffuseAlbedo) */
+    void* SpecularAlbedo;      /* R16G16B16A16_FLOAT   8 B  NRD_MaterialFactors specular (only with PT_GB_SpecularAlbedo) */
     void* NormalRoughness;     /* R16G16B16A16_SNORM   8 B */
     void* IOR;                 /* R16_FLOAT            2 B */
     void* Transmission;        /* R8_UNORM             1 B */

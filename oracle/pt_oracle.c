@@ -1414,6 +1414,23 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
                         tx->BaseColorMetalness[4 * pi + 2] = or_f32_to_unorm8(bs.BaseColor.z);
                         tx->BaseColorMetalness[4 * pi + 3] = or_f32_to_unorm8(bs.Metallic);
                     }
+                    if (flags & OR_GB_Albedo) {
+                        /* BSDFSample::EstimateDemodulationFactors (BxDF.hlsli:317-320) -> NRD_MaterialFactors. [NRD spec] NRD is an
+                         * un-vendored submodule (version unpinned); restated from its published form:
+                         * Fenv = EnvironmentTerm_Rtg(Rf0, |N.V|, roughness); diffuse = (1 - Fenv) * albedo * 0.99 + 0.01;
+                         * specular = Fenv * 0.99 + 0.01. float3 stores to RGBA16F write 0 to alpha. */
+                        const f3 V = neg3(ray.Direction);
+                        const float NoV = fabsf(dot3(h.ShadingNormal, V));
+                        float F0[3] = { bs.F0.x, bs.F0.y, bs.F0.z }, Fe[3];
+                        or_env_term_rtg(F0, NoV, bs.Roughness, Fe);
+                        const float al[3] = { bs.Albedo.x, bs.Albedo.y, bs.Albedo.z };
+                        for (int c = 0; c < 3; c++) {
+                            if ((flags & OR_GB_DiffuseAlbedo) && tx->DiffuseAlbedo) tx->DiffuseAlbedo[4 * pi + c] = or_f32_to_f16((1.0f - Fe[c]) * al[c] * 0.99f + 0.01f);
+                            if ((flags & OR_GB_SpecularAlbedo) && tx->SpecularAlbedo) tx->SpecularAlbedo[4 * pi + c] = or_f32_to_f16(Fe[c] * 0.99f + 0.01f);
+                        }
+                        if ((flags & OR_GB_DiffuseAlbedo) && tx->DiffuseAlbedo) tx->DiffuseAlbedo[4 * pi + 3] = 0;
+                        if ((flags & OR_GB_SpecularAlbedo) && tx->SpecularAlbedo) tx->SpecularAlbedo[4 * pi + 3] = 0;
+                    }
                     if (tx->IOR) tx->IOR[pi] = or_f32_to_f16(m->IOR);
                     if (bs.Metallic < 1.0f && tx->Transmission) tx->Transmission[pi] = or_f32_to_unorm8(bs.Transmission);
                     if ((flags & OR_GB_Radiance) && tx->Radiance) {

@@ -126,8 +126,8 @@ typedef struct OrGBufferTextures {
     float*    NormalizedDepth;     /* R32F */
     uint16_t* MotionVector;        /* RGBA16F   8 B/px */
     uint8_t*  BaseColorMetalness;  /* RGBA8_UNORM */
-    uint16_t* DiffuseAlbedo;       /* unused (denoiser only) */
-    uint16_t* SpecularAlbedo;      /* unused (denoiser only) */
+    uint16_t* DiffuseAlbedo;       /* RGBA16F, only with OR_GB_DiffuseAlbedo */
+    uint16_t* SpecularAlbedo;      /* RGBA16F, only with OR_GB_SpecularAlbedo */
     int16_t*  NormalRoughness;     /* RGBA16_SNORM 8 B/px */
     uint16_t* IOR;                 /* R16F */
     uint8_t*  Transmission;        /* R8_UNORM */

@@ -144,10 +144,14 @@ def test_denoiser_facing_outputs(gpu, ptamd, oracle, pkg):
         r = ptamd.Renderer(gpu, g, W, H, with_f32=True, with_denoiser_outputs=True)
         gpu.reset_counters(); r.render(gs); gpu.sync()
         out = ptamd.textures_to_numpy(r.textures); c = gpu.counters()
-        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, gbuffer_flags=0xFFFFFFFF, accel_mode=0, want_f32=True, layouts=L)   # App.cpp:1223
         assert c.PrimaryRays + c.SecondaryRays == ref_rays
-        for k in ("Radiance", "Diffuse", "Specular", "SpecularHitDistance"):
+        for k in ("Radiance", "Diffuse", "Specular", "SpecularHitDistance", "DiffuseAlbedo", "SpecularAlbedo"):
             assert np.array_equal(out[k], ref_gb[k]), (denoiser, k)
+        # albedo demodulation factors (GBufferGeneration.hlsl:171-186): in [0.01, 1], zero where the primary ray missed
+        da = out["DiffuseAlbedo"].view(np.float16).astype(np.float32)[..., :3]; sa = out["SpecularAlbedo"].view(np.float16).astype(np.float32)[..., :3]
+        hit = np.isfinite(out["LinearDepth"][..., 0])
+        assert hit.any() and (da[hit] >= 0.0099).all() and (da[hit] <= 1.0).all() and (sa[hit] >= 0.0099).all() and (sa[hit] <= 1.0).all()
         if denoiser == L.DENOISER_DLSS_RR:
             d = out["SpecularHitDistance"].view(np.float16).astype(np.float32)
             assert (d > 0).any() and np.isfinite(d).all()
