@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: independent contexts on separate HIP streams, so the launch-bound tail "
                          "rounds of one frame overlap the wide rounds of the next")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="developer aid: skip the per-launch HIP events (and with them the roofline object), so the timed region replays hipGraphs")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="developer aid: render only rank 0's share of an N-rank sharding on one GPU (no gather), to see the per-rank frame time")
     args = ap.parse_args()
@@ -159,7 +161,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    timing = world == 1 and not args.emulate_world          # HIP events around every extend / shade launch (library side)
+    timing = world == 1 and not args.emulate_world and not args.no_kernel_timing          # HIP events around every extend / shade launch (library side)
     for lane in lanes:
         lane.ctx.reset_counters()
         if timing:
@@ -168,6 +170,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         gs = step(args.warmup + i)
+    enqueue_s = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     counters = [lane.ctx.counters() for lane in lanes]
@@ -194,7 +197,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frames_per_s": args.steps / elapsed, "mrays_per_s_per_gpu": rays_total / elapsed / 1e6 / world,
-            "rays_per_frame": rays_total / args.steps,
+            "rays_per_frame": rays_total / args.steps, "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes),
                        "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
                        "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),

@@ -540,33 +540,51 @@ constexpr int kStackLds2 = 16;
 constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u;
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
-template <bool STATS, bool LDS, bool WRITE_T = false>
+template <bool STATS, bool LDS, bool WRITE_T = false, bool FLAT = false>
 __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     if (bq * 256u >= n) return;                                   // block-uniform: nothing to do, skip the staging
     int* ldsStack = (int*)smem;
-    uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
     BlobReader<LDS> blob;
     if constexpr (LDS) {
-        f4v* dst = (f4v*)(smem + kExtendLdsFixed);
+        f4v* dst = (f4v*)(smem + kFixed);
         const uint32_t n16 = bv.bytes / 16u;
         for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = bv.base[i];
         __syncthreads();
-        blob.p = (const PT_LDS_AS f4v*)(smem + kExtendLdsFixed);
+        blob.p = (const PT_LDS_AS f4v*)(smem + kFixed);
     } else {
         blob.p = bv.base;
     }
     TraceStats st; st.nodes = 0; st.tris = 0;
-    for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
-        const uint32_t i = sq * segCap + local;
-        const float4 o = q.r0[i], d = q.r1[i];
-        const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
-        q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
-        if (WRITE_T) q.r1[i].w = h.t;                              // CommittedRayT for the denoiser hit-distance outputs
+    if constexpr (FLAT) {
+        // whole waves enter the traversal (lanes past the end carry a ray that can hit nothing): its lanes trade work items
+        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+        for (uint32_t base = bq * 256u; base < n; base += nbq * 256u) {
+            const uint32_t local = base + threadIdx.x;
+            const bool valid = local < n;
+            const uint32_t i = sq * segCap + (valid ? local : base);
+            float4 o = q.r0[i], d = q.r1[i];
+            if (!valid) { o.w = 1.0f; d.w = 0.0f; }               // empty interval: the scan selects no instance
+            const Hit h = trace_closest_flat<STATS, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st);
+            if (valid) {
+                q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+                if (WRITE_T) q.r1[i].w = h.t;                      // CommittedRayT for the denoiser hit-distance outputs
+            }
+        }
+    } else {
+        uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
+        for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
+            const uint32_t i = sq * segCap + local;
+            const float4 o = q.r0[i], d = q.r1[i];
+            const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
+            q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+            if (WRITE_T) q.r1[i].w = h.t;
+        }
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 }
@@ -728,20 +746,23 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
         const bool lds = c.blob.bytes <= kBlobLdsMax;
-        const uint32_t smem = kExtendLdsFixed + (lds ? c.blob.bytes : 0u);
+        const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
+        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
         if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
         else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
             if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
             else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
-        } else if (aux) {                                              // denoiser modes need CommittedRayT
-            if (lds) k_extend2<false, true, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
-            else k_extend2<false, false, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
-        } else if (lds) {
-            if (stats) k_extend2<true, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
-            else k_extend2<false, true><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
         } else {
-            if (stats) k_extend2<true, false><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
-            else k_extend2<false, false><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            const bool wt = aux != nullptr;                            // denoiser modes need CommittedRayT
+            #define PT_EXT2(S, L, W, F) k_extend2<S, L, W, F><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters)
+            #define PT_EXT2_F(S, L, W) do { if (flat) PT_EXT2(S, L, W, true); else PT_EXT2(S, L, W, false); } while (0)
+            #define PT_EXT2_W(S, L) do { if (wt) PT_EXT2_F(S, L, true); else PT_EXT2_F(S, L, false); } while (0)
+            #define PT_EXT2_L(S) do { if (lds) PT_EXT2_W(S, true); else PT_EXT2_W(S, false); } while (0)
+            if (stats) PT_EXT2_L(true); else PT_EXT2_L(false);
+            #undef PT_EXT2_L
+            #undef PT_EXT2_W
+            #undef PT_EXT2_F
+            #undef PT_EXT2
         }
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }
@@ -772,7 +793,9 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     }
     FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
     k_set_constants<<<1, 192, 0, c.stream>>>(fc, c.frameConstants);
-    const uint32_t grid = persistent_grid(c.device);
+    // persistent grid, but never more blocks than the queue has tiles: surplus blocks only cost dispatch slots and LDS that
+    // a concurrent frame's kernels (other streams) could use -- this matters for small shards (1/8 of a 1080p frame = 1013 tiles)
+    const uint32_t grid = std::min(persistent_grid(c.device), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
     c.lastIterations = rounds + 1;
 
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.

@@ -57,7 +57,15 @@ constexpr uint32_t kLeafTris = 4;            // triangles per BLAS leaf (count f
 PT_DEV int blas_root_entry(uint32_t triCount) { return triCount <= kLeafTris ? ~(int)(triCount - 1u) : 0; }   // triCount >= 1
 PT_DEV int tlas_root_entry(uint32_t instCount) { return instCount == 1u ? ~0 : 0; }                            // instCount >= 1
 
-struct RaySetup { int kx, ky, kz; float Sx, Sy, Sz; };
+// Per-ray constants of the watertight test. kz = dominant axis of the direction (c2: z, else c1: y, else x),
+// kx = kz + 1, ky = kz + 2 (mod 3). The paper additionally swaps kx and ky when d[kz] < 0 to keep the winding; that swap
+// negates U, V, W, det and T exactly (IEEE negation commutes with every operation used) and therefore changes neither the
+// hit decision nor t = T/det, u = V/det, v = W/det: it is omitted here, the results stay bit-identical to the oracle's,
+// which keeps the swap.
+struct RaySetup { bool c1, c2; float Sx, Sy, Sz; };
+PT_DEV float sel_kz(v3 v, const RaySetup& r) { return r.c2 ? v.z : (r.c1 ? v.y : v.x); }
+PT_DEV float sel_kx(v3 v, const RaySetup& r) { return r.c2 ? v.x : (r.c1 ? v.z : v.y); }
+PT_DEV float sel_ky(v3 v, const RaySetup& r) { return r.c2 ? v.y : (r.c1 ? v.x : v.z); }
 
 // Traversal stack: the first LDS_DEPTH entries of every lane live in LDS (entry d of thread t at
 // lds[d * blockDim + t]: consecutive lanes hit consecutive banks), deeper entries spill to a private array.
@@ -83,17 +91,12 @@ struct TraversalStack {
 PT_DEV RaySetup ray_setup(v3 d)
 {
     RaySetup r;
-    int kz = 0; float m = fabsf(d.x);
-    if (fabsf(d.y) > m) { kz = 1; m = fabsf(d.y); }
-    if (fabsf(d.z) > m) { kz = 2; }
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    float dz = comp(d, kz);
-    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
-    r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sz = 1.0f / dz;                    // one IEEE division; Sx, Sy by multiplication (spec, same in the oracle)
-    r.Sx = comp(d, kx) * r.Sz;
-    r.Sy = comp(d, ky) * r.Sz;
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    r.c1 = ay > ax;
+    r.c2 = az > (r.c1 ? ay : ax);
+    r.Sz = 1.0f / sel_kz(d, r);          // one IEEE division; Sx, Sy by multiplication (spec, same in the oracle)
+    r.Sx = sel_kx(d, r) * r.Sz;
+    r.Sy = sel_ky(d, r) * r.Sz;
     return r;
 }
 
@@ -111,17 +114,22 @@ __device__ __attribute__((noinline)) void tri_edge_fallback(float Ax, float Ay, 
 
 // Per-triangle part; fp64 recomputation of the edge functions when one is exactly 0 (paper's
 // fallback) keeps shared edges watertight. Returns t,u,v (u weights v1, v weights v2: DXR barycentrics).
+typedef float f2p __attribute__((ext_vector_type(2)));       // maps to v_pk_{add,mul}_f32 on gfx950: same IEEE results, half the issue slots
 PT_DEV bool tri_test(const RaySetup& r, v3 o, v3 v0, v3 v1, v3 v2, float& t, float& u, float& v)
 {
-    v3 A = v0 - o, B = v1 - o, C = v2 - o;
-    float Akz = comp(A, r.kz), Bkz = comp(B, r.kz), Ckz = comp(C, r.kz);
-    float Ax = comp(A, r.kx) - r.Sx * Akz, Ay = comp(A, r.ky) - r.Sy * Akz;
-    float Bx = comp(B, r.kx) - r.Sx * Bkz, By = comp(B, r.ky) - r.Sy * Bkz;
-    float Cx = comp(C, r.kx) - r.Sx * Ckz, Cy = comp(C, r.ky) - r.Sy * Ckz;
-    float U = Cx * By - Cy * Bx;
-    float V = Ax * Cy - Ay * Cx;
-    float W = Bx * Ay - By * Ax;
-    if (__builtin_expect(U == 0.0f || V == 0.0f || W == 0.0f, 0)) tri_edge_fallback(Ax, Ay, Bx, By, Cx, Cy, U, V, W);
+    const f2p oxy = { o.x, o.y };
+    const f2p Axy = (f2p){ v0.x, v0.y } - oxy, Bxy = (f2p){ v1.x, v1.y } - oxy, Cxy = (f2p){ v2.x, v2.y } - oxy;
+    const v3 A = V3(Axy.x, Axy.y, v0.z - o.z), B = V3(Bxy.x, Bxy.y, v1.z - o.z), C = V3(Cxy.x, Cxy.y, v2.z - o.z);
+    float Akz = sel_kz(A, r), Bkz = sel_kz(B, r), Ckz = sel_kz(C, r);
+    const f2p S = { r.Sx, r.Sy };
+    const f2p a = (f2p){ sel_kx(A, r), sel_ky(A, r) } - S * Akz;       // (Ax, Ay)
+    const f2p b = (f2p){ sel_kx(B, r), sel_ky(B, r) } - S * Bkz;
+    const f2p c = (f2p){ sel_kx(C, r), sel_ky(C, r) } - S * Ckz;
+    const f2p pu = c * b.yx, pv = a * c.yx, pw = b * a.yx;               // (Cx*By, Cy*Bx) ...
+    float U = pu.x - pu.y;
+    float V = pv.x - pv.y;
+    float W = pw.x - pw.y;
+    if (__builtin_expect(U == 0.0f || V == 0.0f || W == 0.0f, 0)) tri_edge_fallback(a.x, a.y, b.x, b.y, c.x, c.y, U, V, W);
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     float det = U + V + W;
     if (det == 0.0f) return false;
@@ -214,7 +222,7 @@ PT_DEV Hit trace_closest(const AccelView& av, const AlphaContext& ac, v3 o, v3 d
 
     v3 ro = o, rd = d;                               // current-space ray (world, then object)
     v3 idir = safe_inv(rd), ood = ro * idir;
-    RaySetup rs; rs.kx = rs.ky = rs.kz = 0; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
     const BvhNode* nodes = av.tlasNodes;
     const TriPacket* tris = nullptr;
     uint32_t curInst = ~0u;
@@ -291,7 +299,7 @@ PT_DEV bool trace_visibility(const AccelView& av, const AlphaContext& ac, v3 o, 
     if (av.instanceCount == 0) return true;
     v3 ro = o, rd = d;
     v3 idir = safe_inv(rd), ood = ro * idir;
-    RaySetup rs; rs.kx = rs.ky = rs.kz = 0; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
     const BvhNode* nodes = av.tlasNodes;
     const TriPacket* tris = nullptr;
     uint32_t curInst = ~0u;

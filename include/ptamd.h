@@ -312,6 +312,7 @@ int  pt_reset_counters(PtContext* ctx);
 int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_TRAVERSAL_STATS 0x1u
 #define PT_DEBUG_TRAVERSAL_V1   0x4u     /* bounce rays use the interleaved TLAS/BLAS traversal of k_gbuffer instead of the phase-aligned one */
+#define PT_DEBUG_TRAVERSAL_PHASED 0x8u  /* bounce rays: the TLAS-walking phase-aligned schedule even when the scene is small enough for the flat one */
 #define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
