@@ -297,6 +297,31 @@ PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
     return base + prefix;
 }
 
+// Two compactions at once (survivors -> traced region, restarts -> fresh region): one barrier sequence instead of two, and
+// the two returning atomics are issued by different waves, so their round trips (~1 us each) overlap. lds: 16 words.
+PT_DEV void block_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t* lds, uint32_t& slotA, uint32_t& slotB)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    if (lane == 0) { lds[wave] = (uint32_t)__popcll(ma); lds[4 + wave] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+        lds[8] = total ? atomicAdd(counterA, total) : 0u;
+    }
+    if (threadIdx.x == 64) {
+        const uint32_t total = lds[4] + lds[5] + lds[6] + lds[7];
+        lds[9] = total ? atomicAdd(counterB, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t baseA = lds[8], baseB = lds[9];
+    for (uint32_t w = 0; w < wave; w++) { baseA += lds[w]; baseB += lds[4 + w]; }
+    __syncthreads();
+    slotA = baseA + (uint32_t)__popcll(ma & lt);
+    slotB = baseB + (uint32_t)__popcll(mb & lt);
+}
+
 // Per-frame constants (camera, scene data, settings) live in a device buffer written in stream order by
 // k_set_constants, not in kernel arguments: the frame's launch sequence can then be captured once into a
 // hipGraph and replayed for every frame (FrameIndex, jitter, ... change without touching the graph).
@@ -419,7 +444,7 @@ template <bool TEXTURED>
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
 {
-    __shared__ uint32_t lds[8];
+    __shared__ uint32_t lds[16];
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
@@ -451,8 +476,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
             if (goes) toTraced = true;
             else toFresh = end_sample(gs, tx, aux, p);
         }
-        const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
-        const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
+        uint32_t st, sf;
+        block_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], lds, st, sf);
         if (toTraced) {
             store_path(qout, seg + st, p);
             qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
@@ -497,8 +522,8 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
                 if (aux && first) aux[p.pixel].y = lobe == LOBE_DIFFUSE ? 1.0f : 0.0f;       // isDiffuse of the lobe sampled at bounce 0, :237
             } else toFresh = end_sample(gs, tx, aux, p);
         }
-        const uint32_t st = block_reserve(toTraced, &countOut[sq], lds);
-        const uint32_t sf = block_reserve(toFresh, &countOut[kSubQueues + sq], lds);
+        uint32_t st, sf;
+        block_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], lds, st, sf);
         if (toTraced) {
             store_path(qout, seg + st, p);
             qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);
@@ -679,7 +704,7 @@ __global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, RankOffsets ran
 static uint32_t persistent_grid(int device)
 {
     hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
-    const uint32_t g = (uint32_t)p.multiProcessorCount * 8u;
+    const uint32_t g = (uint32_t)p.multiProcessorCount * 8u;      // 1536..4096 blocks perform alike on C2; far fewer or more lose
     return (g + kSubQueues - 1) / kSubQueues * kSubQueues;          // whole number of blocks per sub-queue
 }
 

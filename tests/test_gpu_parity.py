@@ -232,6 +232,30 @@ def test_lbvh_vs_device_brute_force_no_mismatch(gpu, ptamd, pkg):
         assert c.SecondaryRays > W * H and c.BvhMismatches == 0
 
 
+def test_traversal_schedules_agree(gpu, ptamd, pkg):
+    """The three schedules of the bounce-ray traversal (flat instance scan with wave-compacted work items, phase-aligned TLAS
+    walk, interleaved TLAS/BLAS) share tri_test / is_better, so images and ray counts must be identical bit for bit."""
+    S = pkg.scenes
+    W, H = 96, 64
+    scenes = [S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True),       # 9 instances: quads, boxes and a 320-triangle sphere
+              S.cornell_box_textured(env=None, aspect=W / H),                      # alpha-tested candidates inside work items
+              S.instanced_grid(n=5, aspect=W / H)]                                 # 25 instances: still the flat schedule by default
+    for scene in scenes:
+        gs = S.graphics_settings(W, H, spp=3, bounces=7, frame_index=2)
+        results = []
+        for flags in (0, 8, 4):                                                    # default, PT_DEBUG_TRAVERSAL_PHASED, PT_DEBUG_TRAVERSAL_V1
+            gpu.set_sharding(0, 1, 16)
+            g = ptamd.Scene(gpu, scene)
+            r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
+            gpu.set_debug_flags(flags); gpu.reset_counters()
+            r.render(gs); gpu.sync()
+            c = gpu.counters()
+            results.append((ptamd.textures_to_numpy(r.textures)["RadianceF32"].view(np.uint32).copy(), c.SecondaryRays))
+            gpu.set_debug_flags(0)
+        for img, rays in results[1:]:
+            assert rays == results[0][1] and np.array_equal(img, results[0][0])
+
+
 def test_deterministic_and_sharding_invariant(gpu, ptamd, pkg):
     """Run twice: bit-identical. Render as rank r of 3 and of 8: the assembled frame equals the unsharded one
     (RNG seeds and camera rays use global pixel coordinates)."""

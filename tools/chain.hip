@@ -12,12 +12,13 @@ __global__ void k(const unsigned* c, unsigned* out, int spin, unsigned busy)
 int main(int argc, char** argv)
 {
     int S = argc > 1 ? atoi(argv[1]) : 1, grid = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 78, spin = argc > 4 ? atoi(argv[4]) : 0;
-    int ldsBytes = argc > 6 ? atoi(argv[6]) : 30000, reps = 50; unsigned busy = argc > 5 ? atoi(argv[5]) : 1u << 30;
+    int prio = argc > 7 ? atoi(argv[7]) : 0; int ldsBytes = argc > 6 ? atoi(argv[6]) : 30000, reps = 50; unsigned busy = argc > 5 ? atoi(argv[5]) : 1u << 30;
     unsigned* d; hipMalloc(&d, 4096); hipMemset(d, 0, 4096);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
     std::vector<hipStream_t> st(S); std::vector<hipGraphExec_t> ge(S);
     for (int s = 0; s < S; s++) {
-        hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking);
+        if (prio) { int lo, hi; hipDeviceGetStreamPriorityRange(&lo, &hi); int pr = prio == 1 ? hi + (s % (lo - hi + 1)) : (prio == 2 ? hi : (prio == 3 ? lo : (prio == 4 ? (s < 3 ? 0 : hi) : (s % 2 ? hi : 0)))); hipStreamCreateWithPriority(&st[s], hipStreamNonBlocking, pr); if (s == 0) printf("priority range %d..%d\n", lo, hi); }
+        else hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking);
         hipGraph_t g; hipStreamBeginCapture(st[s], hipStreamCaptureModeRelaxed);
         for (int i = 0; i < K; i++) k<<<grid, 256, ldsBytes, st[s]>>>(d, d + 64, spin, busy);
         hipStreamEndCapture(st[s], &g); hipGraphInstantiate(&ge[s], g, nullptr, nullptr, 0); hipGraphDestroy(g);
