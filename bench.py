@@ -93,6 +93,8 @@ def main():
                     help="developer aid: skip the per-launch HIP events (and with them the roofline object), so the timed region replays hipGraphs")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="developer aid: render only rank 0's share of an N-rank sharding on one GPU (no gather), to see the per-rank frame time")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="developer aid for a 1-GPU box: run the N > 1 code path (RCCL process group, gather to rank 0, de-interleave) with world size 1")
     args = ap.parse_args()
 
     import torch
@@ -106,7 +108,16 @@ def main():
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.rehearse_collective
+    # RCCL writes a version banner to stdout when the first communicator comes up; the contract is ONE JSON line on stdout,
+    # so everything until the result is printed goes to stderr at the file-descriptor level (native prints included)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if collective:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     ge.load_package()
@@ -129,12 +140,12 @@ def main():
                 self.ctx.set_sharding(rank, args.emulate_world if args.emulate_world else world, BAND)
                 self.scene = P.Scene(self.ctx, scene, device)
                 self.renderer = P.Renderer(self.ctx, self.scene, W, H)
-                if world > 1:                                   # equal-sized gather pieces
+                if collective:                                  # equal-sized gather pieces
                     self.renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
                     for op in (self.renderer.gbuffer, self.renderer.raytracing):
                         op.Textures = self.renderer.textures
                 self.full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if rank == 0 else None
-                self.gathered = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and world > 1) else None
+                self.gathered = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and collective) else None
             self.stream.synchronize()
 
     lanes = [Lane() for _ in range(max(1, args.inflight))]
@@ -145,7 +156,7 @@ def main():
         gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame_index, ext_flags=ext)
         with torch.cuda.stream(lane.stream):
             lane.renderer.render(gs)
-            if world > 1:
+            if collective:
                 SH.gather_to_root(lane.renderer.textures["Radiance"], rank, world, dist, out=lane.gathered)
                 if rank == 0:
                     lane.ctx.check(lane.ctx.lib.pt_deinterleave_bands(lane.ctx.handle, lane.full.data_ptr(), lane.gathered.data_ptr(),
@@ -154,14 +165,14 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(device)
 
     for i in range(args.warmup):
         step(i)
     barrier()
-    timing = world == 1 and not args.emulate_world and not args.no_kernel_timing          # HIP events around every extend / shade launch (library side)
+    timing = world == 1 and not collective and not args.emulate_world and not args.no_kernel_timing          # HIP events around every extend / shade launch (library side)
     for lane in lanes:
         lane.ctx.reset_counters()
         if timing:
@@ -181,7 +192,7 @@ def main():
 
     rays_local = float(primary + secondary)
     t = torch.tensor([elapsed, rays_local, float(secondary)], dtype=torch.float64, device=device)
-    if world > 1:
+    if collective:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, rays_total, secondary_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
@@ -253,11 +264,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
 
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    os.dup2(2, 1)                                                 # teardown chatter (process group, contexts) stays off stdout too
     for lane in lanes:
         lane.ctx.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
