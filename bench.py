@@ -224,6 +224,15 @@ def main():
             lanes[0].renderer.render(gs)
         cs = ctx.counters()
         ctx.set_debug_flags(0)
+        # one more instrumented pass on ONE lane: with several frames in flight an event pair around a launch also spans
+        # the other lanes' kernels, so the per-launch durations above are upper bounds. Here each launch has the GPU alone.
+        ctx.reset_counters(); ctx.enable_kernel_timing(True)
+        with torch.cuda.stream(lanes[0].stream):
+            for i in range(args.steps):
+                lanes[0].renderer.render(S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=args.warmup + i, ext_flags=ext))
+        torch.cuda.synchronize(device)
+        ks = ctx.kernel_timing(); serial_secondary = float(ctx.counters().SecondaryRays)
+        ctx.enable_kernel_timing(False)
         rays_frame = max(1, cs.SecondaryRays)
         node_b, tri_b = 64, 48
         bvh_bytes_per_ray = (cs.NodesVisited * node_b + cs.TrianglesTested * tri_b) / float(cs.PrimaryRays + cs.SecondaryRays)
@@ -260,6 +269,18 @@ def main():
             "note": "HIP-event time summed over every launch of the timed steps (all frames in flight, so a launch shares the GPU with "
                     "the other lane's kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
         }
+        per_ray = {"k_extend": 48.0 + bvh_bytes_per_ray, "k_shade": 252.0}
+        serial = {}
+        for name, key in (("k_extend", "extend"), ("k_shade", "shade")):
+            ms, n = ks[key + "_ms"], max(1, ks[key + "_launches"])
+            gbps = serial_secondary * per_ray[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            serial[name] = {"avg_launch_ms": ms / n, "launches_timed": n, "achieved": gbps, "frac": gbps / HBM_PEAK_GBS}
+            if name == "k_extend":                                # B_bvh of an LDS-resident scene never reaches HBM: the honest HBM figure is 48 B/ray
+                so = serial_secondary * 48.0 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                serial[name]["state_only"] = {"achieved": so, "frac": so / HBM_PEAK_GBS}
+        result["roofline"]["one_frame_in_flight"] = dict(serial, note="same K steps repeated on a single stream after the timed region: "
+                                                         "per-launch durations without other lanes' kernels inside the event pair "
+                                                         "(these are the figures rocprofv3's per-kernel averages agree with)")
         del rays_frame
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
