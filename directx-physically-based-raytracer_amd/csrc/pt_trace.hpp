@@ -164,7 +164,7 @@ struct AlphaContext {
     const struct InstanceRecord* instances;
 };
 
-__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
+__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v);
 
 // commit() for a candidate of a geometry without D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE: the alpha test runs only
 // for candidates that would otherwise be committed (DXR reports candidates inside the current ray interval).
@@ -206,7 +206,7 @@ PT_DEV float safe_inv1(float d)
 PT_DEV v3 safe_inv(v3 d) { return V3(safe_inv1(d.x), safe_inv1(d.y), safe_inv1(d.z)); }
 
 // TraceRay: closest hit over the two-level structure. stack: per-lane array supplied by the caller.
-__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext& ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
+__device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
 {
     const PtObjectData* od = &ac.objects[ac.instances[inst].instanceID + geom];
     TexCoords tc;
