@@ -172,20 +172,22 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
 // ---------------------------------------------------------------------------------------------
 // Flat variant for scenes with at most kFlatInstances instances (every Cornell-type scene): no TLAS walk.
 //   scan     all lanes test the world boxes of ALL instances in the same (uniform) order -- broadcast loads, no stack, no
-//            divergence -- and keep two bit masks: single-leaf instances (<= kLeafTris triangles, e.g. a quad) and the rest
-//   meshes   every set bit is a work item (ray, instance). The items of the whole wave are compacted into a list in LDS
-//            and lane j processes item j -- not necessarily one of its own ray: a ray that touches two boxes is served by
-//            two lanes at once, a ray that touches none lends its lane to a neighbour. An item = late cull, ray transform +
-//            Woop setup, BLAS-only while-while loop; its closest hit goes back through LDS and the ray's own lane merges
-//            the results of its items with the usual (t, instance, geometry, primitive) order
-//   quads    per set bit, own ray: the same entry, then the leaf's <= 4 triangles -- straight-line code
-// Lanes that hit a 2-triangle wall no longer idle while their neighbours walk a 12-triangle box, and the box walks
-// themselves run with full lanes (before: 1.9 rounds per wave at 38 % occupancy; now: 1 round at ~70 %). Same tri_test /
-// is_better, so the result is bit-identical to the other schedules.
+//            divergence -- and keep two bit masks: meshes and single-leaf instances (<= kLeafTris triangles, e.g. a quad)
+//   items    every set bit is a work item (ray, instance). The items of the whole wave -- meshes first, then quads -- are
+//            compacted into a list in LDS and lane j processes items j, j + 64, ...: not necessarily of its own ray. A ray
+//            that touches two boxes and a wall is served by three lanes at once, a ray that touches one wall lends its lane
+//            to a neighbour. An item = (late cull,) ray transform + Woop setup, BLAS-only while-while loop entered at the
+//            root (meshes) or directly at the only leaf (quads); its closest hit goes back through LDS
+//   merge    the ray's own lane takes the results of its items; ties on t go to the lower instance index (one item per
+//            (ray, instance), so geometry / primitive order is already settled inside the item)
+// Lanes that hit a 2-triangle wall no longer idle while their neighbours walk a 12-triangle box, and both kinds run with
+// full lanes (measured before compaction: 1.9 mesh rounds per wave at 38 % occupancy + 2.4 quad rounds at 54 %; now
+// ~128 items in 2 rounds). Same tri_test / is_better arithmetic, so the result is bit-identical to the other schedules.
 constexpr uint32_t kFlatInstances = 32;
 constexpr int kStackLdsFlat = 8;                                             // BLAS-only stacks are shallow; deeper entries spill
-// LDS per wave for the exchange: rays 64 x 32 B | results 64 x 32 B | items 64 x 4 B
-constexpr uint32_t kFlatWaveLds = 64u * 32u + 64u * 32u + 64u * 4u;
+constexpr uint32_t kFlatItems = 192;                                         // items per batch and wave
+// LDS per wave for the exchange: rays 64 x 32 B | results kFlatItems x 16 B | items kFlatItems x 4 B
+constexpr uint32_t kFlatWaveLds = 64u * 32u + kFlatItems * 16u + kFlatItems * 4u;
 constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 4u + 4u * kFlatWaveLds;
 
 template <bool STATS, bool LDS>
@@ -193,173 +195,166 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
                               int* ldsStack, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
-    const v3 idir = safe_inv(d), ood = o * idir;
     uint32_t quads = 0, meshes = 0;
-    for (uint32_t x = 0; x < bv.instCount; x++) {                           // uniform
-        const uint32_t ia = bv.instOff16 + x * kInst16;
-        const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4), mk = blob.ld(ia + 5);
-        const uint32_t ntri = __float_as_uint(mk.y);
-        if (!(__float_as_uint(mk.x) & 0xFFu) || ntri == 0u) continue;       // uniform
-        const float lx = __builtin_fmaf(b0.x, idir.x, -ood.x), hx = __builtin_fmaf(b1.x, idir.x, -ood.x);
-        const float ly = __builtin_fmaf(b0.y, idir.y, -ood.y), hy = __builtin_fmaf(b1.y, idir.y, -ood.y);
-        const float lz = __builtin_fmaf(b0.z, idir.z, -ood.z), hz = __builtin_fmaf(b1.z, idir.z, -ood.z);
-        const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
-        const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tmax));
-        const uint32_t bit = (tn <= tf * 1.0000004f) ? (1u << x) : 0u;
-        if (ntri <= kLeafTris) quads |= bit; else meshes |= bit;            // uniform select
-    }
-    if (STATS) stats->nodes += (bv.instCount + 1u) / 2u;                    // two boxes = one node's worth of bytes
-
-    // ---------------- meshes: wave-compacted work items
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    f4v* rays = (f4v*)ldsWave;                                              // [lane][2]: o.xyz tmin | d.xyz best t
-    f4v* results = (f4v*)(ldsWave + 64u * 32u);                             // [item][2]: t u v slot | geom prim - -
-    uint32_t* items = (uint32_t*)(ldsWave + 64u * 64u);                     // [item]: lane | instance << 8
-    const uint32_t nm = (uint32_t)__builtin_popcount(meshes);
-    if (__ballot(nm > 0u)) {
-        rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
-        int spill[kStackSize - kStackLdsFlat];
-        TraversalStack<kStackLdsFlat> stack; stack.init(ldsStack, spill);
-        uint32_t todo = meshes;
-        for (uint32_t k = 0; ; ) {                                          // k: levels (k-th set bit of every lane) already done; uniform
-            if (!__ballot(nm > k)) break;
-            rays[2 * lane + 1] = (f4v){ d.x, d.y, d.z, h.t };
-            // one round takes whole levels while they fit into 64 items
-            uint32_t total = 0, k2 = k, bits = todo;
-            while (true) {
-                const unsigned long long bb = __ballot(nm > k2);
-                const uint32_t n = (uint32_t)__builtin_popcountll(bb);
-                if (n == 0u || (total != 0u && total + n > 64u)) break;
-                if (nm > k2) {
-                    const uint32_t x = (uint32_t)__builtin_ctz(bits); bits &= bits - 1u;
-                    items[total + (uint32_t)__builtin_popcountll(bb & ltMask)] = lane | (x << 8);
-                }
-                total += n; k2++;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < total) {
-                const uint32_t it = items[lane];
-                const uint32_t src = it & 0xFFu, x = it >> 8;
-                const f4v r0 = rays[2 * src], r1 = rays[2 * src + 1];
-                const v3 io = V3(r0.x, r0.y, r0.z), id = V3(r1.x, r1.y, r1.z);
-                const float itmin = r0.w, ibest = r1.w;
-                // item-local best: starts at the ray's best t with an id that loses every tie, so a candidate at exactly that t
-                // is kept and the ray's own lane applies the real (instance, geometry, primitive) order when it merges
-                Hit hi; hi.t = ibest; hi.u = 0.0f; hi.v = 0.0f; hi.inst = 0xFFFFFFFEu; hi.geom = ~0u; hi.prim = ~0u; hi.slot = ~0u;
-                const uint32_t ia = bv.instOff16 + x * kInst16;
-                const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
-                bool enter = true;
-                if (k != 0u) {   // late cull against the best hit of earlier rounds (round 0 starts from the scan's verdict)
-                    const v3 iidir = safe_inv(id), iood = io * iidir;
-                    const float lx = __builtin_fmaf(b0.x, iidir.x, -iood.x), hx = __builtin_fmaf(b1.x, iidir.x, -iood.x);
-                    const float ly = __builtin_fmaf(b0.y, iidir.y, -iood.y), hy = __builtin_fmaf(b1.y, iidir.y, -iood.y);
-                    const float lz = __builtin_fmaf(b0.z, iidir.z, -iood.z), hz = __builtin_fmaf(b1.z, iidir.z, -iood.z);
-                    const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), itmin));
-                    const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), ibest));
-                    enter = tn <= tf * 1.0000004f;
-                }
-                if (enter) {
-                    const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
-                    const v3 ro = V3(w0.x * io.x + w0.y * io.y + w0.z * io.z + w0.w,
-                                     w1.x * io.x + w1.y * io.y + w1.z * io.z + w1.w,
-                                     w2.x * io.x + w2.y * io.y + w2.z * io.z + w2.w);
-                    const v3 rd = V3(w0.x * id.x + w0.y * id.y + w0.z * id.z,
-                                     w1.x * id.x + w1.y * id.y + w1.z * id.z,
-                                     w2.x * id.x + w2.y * id.y + w2.z * id.z);
-                    const RaySetup rs = ray_setup(rd);
-                    const v3 bidir = safe_inv(rd), bood = ro * bidir;
-                    const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-                    const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-                    stack.sp = 0;
-                    stack.push(kEntryRestore);
-                    int c = 0;
-                    while (true) {
-                        while (c >= 0 && c < kEntryRestore) {
-                            const uint32_t a = nodeBase + (uint32_t)c * kNode16;
-                            const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
-                            if (STATS) stats->nodes++;
-                            bool h0, h1; float t0, t1;
-                            node_test_v(n0, n1, n2, bidir, bood, itmin, hi.t, h0, h1, t0, t1);
-                            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                            if (h0 && h1) {
-                                int nearc = c0, farc = c1;
-                                if (t1 < t0) { nearc = c1; farc = c0; }
-                                stack.push(farc);
-                                c = nearc;
-                            } else if (h0) c = c0;
-                            else if (h1) c = c1;
-                            else c = stack.pop();
-                        }
-                        if (c == kEntryRestore) break;
-                        const uint32_t leaf = (uint32_t)~c;
-                        const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                        for (uint32_t i = 0; i < count; i++) {
-                            const uint32_t ta = triBase + (first + i) * kTri16;
-                            const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
-                            if (STATS) stats->tris++;
-                            float t, u, v;
-                            if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                                commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
-                        }
-                        c = stack.pop();
-                    }
-                }
-                results[2 * lane] = (f4v){ hi.t, hi.u, hi.v, __uint_as_float(hi.slot) };        // slot == ~0u: nothing committed
-                results[2 * lane + 1] = (f4v){ __uint_as_float(hi.geom), __uint_as_float(hi.prim), 0.0f, 0.0f };
-            }
-            __builtin_amdgcn_wave_barrier();
-            // merge: every ray takes the results of its items of levels [k, k2), in instance order
-            uint32_t off = 0;
-            for (uint32_t kk = k; kk < k2; kk++) {
-                const unsigned long long bb = __ballot(nm > kk);
-                if (nm > kk) {
-                    const uint32_t x = (uint32_t)__builtin_ctz(todo); todo &= todo - 1u;
-                    const uint32_t idx = off + (uint32_t)__builtin_popcountll(bb & ltMask);
-                    const f4v q0 = results[2 * idx], q1 = results[2 * idx + 1];
-                    const uint32_t slot = __float_as_uint(q0.w);
-                    if (slot != ~0u) commit(h, tmin, q0.x, q0.y, q0.z, x, __float_as_uint(q1.x), __float_as_uint(q1.y), slot);
-                }
-                off += (uint32_t)__builtin_popcountll(bb);
-            }
-            __builtin_amdgcn_wave_barrier();
-            k = k2;
-        }
-    }
-
-    // ---------------- quads: own ray, straight-line
-    uint32_t todo = quads;
-    while (todo) {
-        const uint32_t x = (uint32_t)__builtin_ctz(todo);
-        todo &= todo - 1u;
-        const uint32_t ia = bv.instOff16 + x * kInst16;
-        const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
-        {   // late cull against the current best hit
+    {
+        const v3 idir = safe_inv(d), ood = o * idir;
+        for (uint32_t x = 0; x < bv.instCount; x++) {                       // uniform
+            const uint32_t ia = bv.instOff16 + x * kInst16;
+            const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4), mk = blob.ld(ia + 5);
+            const uint32_t ntri = __float_as_uint(mk.y);
+            if (!(__float_as_uint(mk.x) & 0xFFu) || ntri == 0u) continue;   // uniform
             const float lx = __builtin_fmaf(b0.x, idir.x, -ood.x), hx = __builtin_fmaf(b1.x, idir.x, -ood.x);
             const float ly = __builtin_fmaf(b0.y, idir.y, -ood.y), hy = __builtin_fmaf(b1.y, idir.y, -ood.y);
             const float lz = __builtin_fmaf(b0.z, idir.z, -ood.z), hz = __builtin_fmaf(b1.z, idir.z, -ood.z);
             const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
-            const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
-            if (!(tn <= tf * 1.0000004f)) continue;
+            const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tmax));
+            const uint32_t bit = (tn <= tf * 1.0000004f) ? (1u << x) : 0u;
+            if (ntri <= kLeafTris) quads |= bit; else meshes |= bit;        // uniform select
         }
-        const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
-        const v3 ro = V3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w,
-                         w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
-                         w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
-        const v3 rd = V3(w0.x * d.x + w0.y * d.y + w0.z * d.z,
-                         w1.x * d.x + w1.y * d.y + w1.z * d.z,
-                         w2.x * d.x + w2.y * d.y + w2.z * d.z);
-        const RaySetup rs = ray_setup(rd);
-        const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-        const uint32_t count = __float_as_uint(blob.ld(ia + 5).y);
-        for (uint32_t i = 0; i < count; i++) {
-            const uint32_t ta = triBase + i * kTri16;
-            const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
-            if (STATS) stats->tris++;
-            float t, u, v;
-            if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), i);
+        if (STATS) stats->nodes += (bv.instCount + 1u) / 2u;                // two boxes = one node's worth of bytes
+    }
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    f4v* rays = (f4v*)ldsWave;                                              // [lane][2]: o.xyz tmin | d.xyz best t
+    f4v* results = (f4v*)(ldsWave + 64u * 32u);                             // [item]: t u v slot
+    uint32_t* items = (uint32_t*)(ldsWave + 64u * 32u + kFlatItems * 16u);  // [item]: lane | instance << 8
+    const uint32_t nm = (uint32_t)__builtin_popcount(meshes), nq = (uint32_t)__builtin_popcount(quads);
+    if (!__ballot((nm | nq) != 0u)) return h;
+    rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
+    int spill[kStackSize - kStackLdsFlat];
+    TraversalStack<kStackLdsFlat> stack; stack.init(ldsStack, spill);
+
+    uint32_t km = 0, kq = 0;                                                // levels (k-th set bit of every lane) already done; uniform
+    bool firstBatch = true;
+    while (true) {
+        // ---- a batch: whole levels, meshes before quads, while they fit
+        uint32_t total = 0, km2 = km, kq2 = kq;
+        {
+            uint32_t mb = meshes, qb = quads;
+            while (true) {
+                const unsigned long long bb = __ballot(nm > km2);
+                const uint32_t n = (uint32_t)__builtin_popcountll(bb);
+                if (n == 0u || total + n > kFlatItems) break;
+                if (nm > km2) {
+                    const uint32_t x = (uint32_t)__builtin_ctz(mb); mb &= mb - 1u;
+                    items[total + (uint32_t)__builtin_popcountll(bb & ltMask)] = lane | (x << 8);
+                }
+                total += n; km2++;
+            }
+            if (!__ballot(nm > km2)) {                                      // every mesh level is in: quads may follow
+                while (true) {
+                    const unsigned long long bb = __ballot(nq > kq2);
+                    const uint32_t n = (uint32_t)__builtin_popcountll(bb);
+                    if (n == 0u || total + n > kFlatItems) break;
+                    if (nq > kq2) {
+                        const uint32_t x = (uint32_t)__builtin_ctz(qb); qb &= qb - 1u;
+                        items[total + (uint32_t)__builtin_popcountll(bb & ltMask)] = lane | (x << 8);
+                    }
+                    total += n; kq2++;
+                }
+            }
         }
+        if (total == 0u) break;                                             // nothing left (a level never exceeds 64 <= kFlatItems)
+        rays[2 * lane + 1] = (f4v){ d.x, d.y, d.z, h.t };
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- process: lane j takes items j, j + 64, ...
+        for (uint32_t j = lane; j < total; j += 64u) {
+            const uint32_t it = items[j];
+            const uint32_t src = it & 0xFFu, x = it >> 8;
+            const f4v r0 = rays[2 * src], r1 = rays[2 * src + 1];
+            const v3 io = V3(r0.x, r0.y, r0.z), id = V3(r1.x, r1.y, r1.z);
+            const float itmin = r0.w, ibest = r1.w;
+            // item-local best: starts at the ray's best t with an id that loses every tie, so a candidate at exactly that t
+            // is kept and the ray's own lane applies the instance order when it merges
+            Hit hi; hi.t = ibest; hi.u = 0.0f; hi.v = 0.0f; hi.inst = 0xFFFFFFFEu; hi.geom = ~0u; hi.prim = ~0u; hi.slot = ~0u;
+            const uint32_t ia = bv.instOff16 + x * kInst16;
+            const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
+            bool enter = true;
+            if (!firstBatch) {       // late cull against the best hit of earlier batches (the first starts from the scan's verdict)
+                const v3 iidir = safe_inv(id), iood = io * iidir;
+                const float lx = __builtin_fmaf(b0.x, iidir.x, -iood.x), hx = __builtin_fmaf(b1.x, iidir.x, -iood.x);
+                const float ly = __builtin_fmaf(b0.y, iidir.y, -iood.y), hy = __builtin_fmaf(b1.y, iidir.y, -iood.y);
+                const float lz = __builtin_fmaf(b0.z, iidir.z, -iood.z), hz = __builtin_fmaf(b1.z, iidir.z, -iood.z);
+                const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), itmin));
+                const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), ibest));
+                enter = tn <= tf * 1.0000004f;
+            }
+            if (enter) {
+                const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
+                const v3 ro = V3(w0.x * io.x + w0.y * io.y + w0.z * io.z + w0.w,
+                                 w1.x * io.x + w1.y * io.y + w1.z * io.z + w1.w,
+                                 w2.x * io.x + w2.y * io.y + w2.z * io.z + w2.w);
+                const v3 rd = V3(w0.x * id.x + w0.y * id.y + w0.z * id.z,
+                                 w1.x * id.x + w1.y * id.y + w1.z * id.z,
+                                 w2.x * id.x + w2.y * id.y + w2.z * id.z);
+                const RaySetup rs = ray_setup(rd);
+                const v3 bidir = safe_inv(rd), bood = ro * bidir;
+                const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+                const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
+                stack.sp = 0;
+                stack.push(kEntryRestore);
+                int c = blas_root_entry(__float_as_uint(blob.ld(ia + 5).y));      // quads: straight to their only leaf
+                while (true) {
+                    while (c >= 0 && c < kEntryRestore) {
+                        const uint32_t a = nodeBase + (uint32_t)c * kNode16;
+                        const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
+                        if (STATS) stats->nodes++;
+                        bool h0, h1; float t0, t1;
+                        node_test_v(n0, n1, n2, bidir, bood, itmin, hi.t, h0, h1, t0, t1);
+                        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                        if (h0 && h1) {
+                            int nearc = c0, farc = c1;
+                            if (t1 < t0) { nearc = c1; farc = c0; }
+                            stack.push(farc);
+                            c = nearc;
+                        } else if (h0) c = c0;
+                        else if (h1) c = c1;
+                        else c = stack.pop();
+                    }
+                    if (c == kEntryRestore) break;
+                    const uint32_t leaf = (uint32_t)~c;
+                    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+                    for (uint32_t i = 0; i < count; i++) {
+                        const uint32_t ta = triBase + (first + i) * kTri16;
+                        const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+                        if (STATS) stats->tris++;
+                        float t, u, v;
+                        if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
+                            commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
+                    }
+                    c = stack.pop();
+                }
+            }
+            results[j] = (f4v){ hi.t, hi.u, hi.v, __uint_as_float(hi.slot) };                   // slot == ~0u: nothing committed
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- merge: every ray takes the results of its items of this batch, in the order they were listed
+        {
+            uint32_t off = 0;
+            for (uint32_t pass = 0; pass < 2u; pass++) {
+                const uint32_t ka = pass == 0u ? km : kq, kb = pass == 0u ? km2 : kq2, mine = pass == 0u ? nm : nq;
+                for (uint32_t kk = ka; kk < kb; kk++) {
+                    const unsigned long long bb = __ballot(mine > kk);
+                    if (mine > kk) {
+                        uint32_t x;
+                        if (pass == 0u) { x = (uint32_t)__builtin_ctz(meshes); meshes &= meshes - 1u; }
+                        else { x = (uint32_t)__builtin_ctz(quads); quads &= quads - 1u; }
+                        const f4v q = results[off + (uint32_t)__builtin_popcountll(bb & ltMask)];
+                        const uint32_t slot = __float_as_uint(q.w);
+                        // is_better() with the instance as the whole tie-break: two results of a ray never share an instance
+                        if (slot != ~0u && q.x > tmin && (q.x < h.t || (q.x == h.t && h.inst != ~0u && x < h.inst))) {
+                            h.t = q.x; h.u = q.y; h.v = q.z; h.inst = x; h.slot = slot;
+                        }
+                    }
+                    off += (uint32_t)__builtin_popcountll(bb);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        km = km2; kq = kq2; firstBatch = false;
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;
