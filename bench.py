@@ -93,6 +93,8 @@ def main():
                     help="developer aid: skip the per-launch HIP events (and with them the roofline object), so the timed region replays hipGraphs")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="developer aid: render only rank 0's share of an N-rank sharding on one GPU (no gather), to see the per-rank frame time")
+    ap.add_argument("--unfused", action="store_true",
+                    help="developer aid: a round as two launches (k_shade + k_extend2) instead of the fused k_round, to profile the halves separately")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="developer aid for a 1-GPU box: run the N > 1 code path (RCCL process group, gather to rank 0, de-interleave) with world size 1")
     args = ap.parse_args()
@@ -150,6 +152,9 @@ def main():
 
     lanes = [Lane() for _ in range(max(1, args.inflight))]
     ctx = lanes[0].ctx
+    BASE_FLAGS = 0x10 if args.unfused else 0                   # PT_DEBUG_UNFUSED_ROUNDS
+    for lane in lanes:
+        lane.ctx.set_debug_flags(BASE_FLAGS)
 
     def step(frame_index):
         lane = lanes[frame_index % len(lanes)]
@@ -218,12 +223,12 @@ def main():
     # ---- roofline of the dominant kernel (N = 1): one extra frame with traversal statistics for B_bvh
     if rank == 0 and timing:
         kt = {k: sum(x[k] for x in kts) for k in kts[0]}
-        ctx.set_debug_flags(1)
+        ctx.set_debug_flags(1 | BASE_FLAGS)
         ctx.reset_counters()
         with torch.cuda.stream(lanes[0].stream):
             lanes[0].renderer.render(gs)
         cs = ctx.counters()
-        ctx.set_debug_flags(0)
+        ctx.set_debug_flags(BASE_FLAGS)
         # one more instrumented pass on ONE lane: with several frames in flight an event pair around a launch also spans
         # the other lanes' kernels, so the per-launch durations above are upper bounds. Here each launch has the GPU alone.
         ctx.reset_counters(); ctx.enable_kernel_timing(True)
@@ -236,17 +241,28 @@ def main():
         rays_frame = max(1, cs.SecondaryRays)
         node_b, tri_b = 64, 48
         bvh_bytes_per_ray = (cs.NodesVisited * node_b + cs.TrianglesTested * tri_b) / float(cs.PrimaryRays + cs.SecondaryRays)
-        ext_ms, sh_ms = kt["extend_ms"], kt["shade_ms"]
         sec_rays = secondary_total
-        # algorithmic bytes per secondary ray (DESIGN.md / SURVEY 8d): extend = ray read 32 + hit write 16 + B_bvh;
-        # shade = ray write 32 + hit read 16 + path state 48 r + 48 w + hit geometry 108
-        kernels = {
-            "k_extend": {"ms": ext_ms, "launches": kt["extend_launches"], "bytes": sec_rays * (48.0 + bvh_bytes_per_ray)},
-            "k_shade": {"ms": sh_ms, "launches": kt["shade_launches"], "bytes": sec_rays * 252.0},
-        }
+        # algorithmic bytes per secondary ray (DESIGN.md / SURVEY 8d). Fused round (the product path): ray read 32 + path state
+        # 48 r + 48 w + ray write 32 + hit geometry 108 + B_bvh = 268 + B_bvh (the 16 B hit record stays in registers).
+        # Two-kernel form (--unfused): extend = ray read 32 + hit write 16 + B_bvh; shade = hit read 16 + ray dir 16 + state 96 + ray write 32 + geometry 108
+        STATE = {"k_round": 268.0, "k_extend": 48.0, "k_shade": 252.0}
+        WITH_BVH = {"k_round", "k_extend"}
+
+        def kernel_table(t, rays):
+            tab = {}
+            for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
+                if t.get(key + "_launches", 0):
+                    per_ray = STATE[name] + (bvh_bytes_per_ray if name in WITH_BVH else 0.0)
+                    tab[name] = {"ms": t[key + "_ms"], "launches": t[key + "_launches"], "bytes": rays * per_ray, "state_bytes": rays * STATE[name]}
+            return tab
+
+        def gbps(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        kernels = kernel_table(kt, sec_rays)
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         kd = kernels[dom]
-        achieved = kd["bytes"] / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0
+        achieved = gbps(kd["bytes"], kd["ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -258,26 +274,21 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "state_only": {"achieved": (sec_rays * (48.0 if dom == "k_extend" else 252.0)) / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0,
-                           "note": "queue/state bytes only, without B_bvh (BVH bytes of a cache-resident scene never reach HBM)"},
+            "state_only": {"achieved": gbps(kd["state_bytes"], kd["ms"]), "frac": gbps(kd["state_bytes"], kd["ms"]) / HBM_PEAK_GBS,
+                           "note": "queue/state bytes only, without B_bvh (BVH bytes of an LDS- or cache-resident scene never reach HBM)"},
             "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
             "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
             "bvh_bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / float(cs.PrimaryRays + cs.SecondaryRays),
             "tris_per_ray": cs.TrianglesTested / float(cs.PrimaryRays + cs.SecondaryRays),
-            "other_kernel": {k: {"ms_total": v["ms"], "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)}
-                             for k, v in kernels.items() if k != dom},
+            "other_kernel": {k: {"ms_total": v["ms"], "GBps": gbps(v["bytes"], v["ms"])} for k, v in kernels.items() if k != dom},
             "note": "HIP-event time summed over every launch of the timed steps (all frames in flight, so a launch shares the GPU with "
-                    "the other lane's kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
+                    "the other lanes' kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
         }
-        per_ray = {"k_extend": 48.0 + bvh_bytes_per_ray, "k_shade": 252.0}
         serial = {}
-        for name, key in (("k_extend", "extend"), ("k_shade", "shade")):
-            ms, n = ks[key + "_ms"], max(1, ks[key + "_launches"])
-            gbps = serial_secondary * per_ray[name] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            serial[name] = {"avg_launch_ms": ms / n, "launches_timed": n, "achieved": gbps, "frac": gbps / HBM_PEAK_GBS}
-            if name == "k_extend":                                # B_bvh of an LDS-resident scene never reaches HBM: the honest HBM figure is 48 B/ray
-                so = serial_secondary * 48.0 / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                serial[name]["state_only"] = {"achieved": so, "frac": so / HBM_PEAK_GBS}
+        for name, v in kernel_table(ks, serial_secondary).items():
+            g = gbps(v["bytes"], v["ms"]); so = gbps(v["state_bytes"], v["ms"])
+            serial[name] = {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": g, "frac": g / HBM_PEAK_GBS,
+                            "state_only": {"achieved": so, "frac": so / HBM_PEAK_GBS}}
         result["roofline"]["one_frame_in_flight"] = dict(serial, note="same K steps repeated on a single stream after the timed region: "
                                                          "per-launch durations without other lanes' kernels inside the event pair "
                                                          "(these are the figures rocprofv3's per-kernel averages agree with)")

@@ -88,6 +88,7 @@ void pt_destroy(PtContext* ctx)
     if (c.queueCounts) hipFree(c.queueCounts);
     if (c.counters) hipFree(c.counters);
     for (auto e : c.evExtend) hipEventDestroy(e);
+    for (auto e : c.evRound) hipEventDestroy(e);
     for (auto e : c.evShade) hipEventDestroy(e);
     delete ctx;
 }
@@ -501,7 +502,7 @@ int pt_enable_kernel_timing(PtContext* ctx, int enable)
 {
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     ctx->c.timing = enable != 0;
-    ctx->c.nExtend = ctx->c.nShade = 0;          // accumulation restarts
+    ctx->c.nExtend = ctx->c.nShade = ctx->c.nRound = 0;          // accumulation restarts
     return PT_OK;
 }
 
@@ -520,6 +521,20 @@ int pt_get_kernel_timing(PtContext* ctx, float* extend_ms, float* shade_ms, uint
     if (shade_ms) *shade_ms = ts;
     if (extend_launches) *extend_launches = c.nExtend;
     if (shade_launches) *shade_launches = c.nShade;
+    return PT_OK;
+}
+
+int pt_get_round_timing(PtContext* ctx, float* round_ms, uint32_t* round_launches)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    float t = 0.0f;
+    if (c.timing)
+        for (uint32_t k = 0; k < c.nRound && 2 * k + 1 < c.evRound.size(); k++) { float ms = 0; hipEventElapsedTime(&ms, c.evRound[2 * k], c.evRound[2 * k + 1]); t += ms; }
+    if (round_ms) *round_ms = t;
+    if (round_launches) *round_launches = c.nRound;
     return PT_OK;
 }
 

@@ -91,8 +91,8 @@ struct Context {
     uint32_t debugFlags = 0;
 
     bool timing = false;
-    std::vector<hipEvent_t> evExtend, evShade;     // begin/end pairs of the last frame
-    uint32_t nExtend = 0, nShade = 0;
+    std::vector<hipEvent_t> evExtend, evShade, evRound;     // begin/end pairs since timing was enabled
+    uint32_t nExtend = 0, nShade = 0, nRound = 0;
 };
 
 // pt_bvh.hip

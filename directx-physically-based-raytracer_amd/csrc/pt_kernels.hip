@@ -439,6 +439,76 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const
     return false;
 }
 
+// ---- the bodies of k_shade, shared with the fused round kernel k_round ----------------------------------------
+// A traced path at its hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304. hit = (instance, triangle slot, u, v).
+template <bool TEXTURED>
+PT_DEV void shade_traced(const SceneView& sv, const PtSceneData& sd, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
+                         PathRegs& p, uint4 hr, float hitT, v3 rayDir, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
+{
+    bool goes = false; int lobe = 0;
+    if (aux && p.sample == 0 && p.bounce == 1) aux[p.pixel].x = hr.x == ~0u ? INFINITY : hitT;        // hitDistance, :235-239
+    if (hr.x == ~0u) {                                       // :241-259
+        p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
+    } else {                                                 // :293-304
+        SurfaceHit h;
+        reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+        const PtMaterial m = surface_material<TEXTURED>(sv, h);
+        BSDFSample bs;
+        bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
+        goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD, lobe);
+    }
+    if (goes) toTraced = true;
+    else toFresh = end_sample(gs, tx, aux, p);
+}
+
+// A fresh path: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
+PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
+                        PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
+{
+    const uint32_t pixel = p.pixel;
+    const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
+    float uu, vv;
+    const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
+    const v3 rayDir = primaryRay.d;
+    const float4 pos = ((const float4*)tx.Position)[pixel];
+    const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
+    const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
+    const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
+    const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
+    SurfaceHit h;
+    h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;                  // HitInfo.hlsli:67-79
+    h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
+    h.GeometricNormal = oct_decode(snorm16_to_f32(ge.x), snorm16_to_f32(ge.y));
+    h.ShadingNormal = V3(snorm16_to_f32(nr.x), snorm16_to_f32(nr.y), snorm16_to_f32(nr.z));
+    h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
+    const v3 emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));           // :119,197
+    const float metal = unorm8_to_f32(bcm.w);
+    const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
+    const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
+    BSDFSample bs;
+    bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
+    int lobe = 0;
+    const bool first = p.sample == 0;
+    if (scatter(gs, p, h, bs, emission, rayDir, newO, newD, lobe)) {
+        toTraced = true;
+        if (aux && first) aux[p.pixel].y = lobe == LOBE_DIFFUSE ? 1.0f : 0.0f;       // isDiffuse of the lobe sampled at bounce 0, :237
+    } else toFresh = end_sample(gs, tx, aux, p);
+}
+
+// compaction + stores of one tile: survivors to the traced region (state + ray), restarts to the fresh region (state)
+PT_DEV void emit_tile(const PathQueue& qout, uint32_t seg, uint32_t segCap, uint32_t* countTraced, uint32_t* countFresh, uint32_t* lds,
+                      bool toTraced, bool toFresh, const PathRegs& p, v3 newO, v3 newD)
+{
+    uint32_t st, sf;
+    block_reserve2(toTraced, toFresh, countTraced, countFresh, lds, st, sf);
+    if (toTraced) {
+        store_path(qout, seg + st, p);
+        qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
+        qout.r1[seg + st] = make_float4(newD.x, newD.y, newD.z, INFINITY);                // TMax = inf, :224
+    }
+    if (toFresh) store_path(qout, seg + (segCap - 1u - sf), p);
+}
+
 // counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
@@ -450,8 +520,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
     const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
     const uint32_t seg = sq * segCap;
 
-    // ---- traced paths: the hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304
-    for (uint32_t tile = bq; tile * 256u < nT; tile += nbq) {
+    for (uint32_t tile = bq; tile * 256u < nT; tile += nbq) {                // traced entries: hit records left by k_extend
         const uint32_t local = tile * 256u + threadIdx.x;
         const uint32_t i = seg + local;
         bool toTraced = false, toFresh = false;
@@ -459,77 +528,20 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
         if (local < nT) {
             p = load_path(qin, i);
             const uint4 hr = qin.hit[i];
-            const float4 rd = qin.r1[i];
-            const v3 rayDir = V3(rd.x, rd.y, rd.z);
-            bool goes = false; int lobe = 0;
-            if (aux && p.sample == 0 && p.bounce == 1) aux[p.pixel].x = hr.x == ~0u ? INFINITY : rd.w;     // hitDistance, :235-239 (k_extend left t in r1.w)
-            if (hr.x == ~0u) {                                   // :241-259
-                p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
-            } else {                                             // :293-304
-                SurfaceHit h;
-                reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
-                const PtMaterial m = surface_material<TEXTURED>(sv, h);
-                BSDFSample bs;
-                bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
-                goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD, lobe);
-            }
-            if (goes) toTraced = true;
-            else toFresh = end_sample(gs, tx, aux, p);
+            const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
+            shade_traced<TEXTURED>(sv, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
-        uint32_t st, sf;
-        block_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], lds, st, sf);
-        if (toTraced) {
-            store_path(qout, seg + st, p);
-            qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);                    // TMin = 0, :223
-            qout.r1[seg + st] = make_float4(newD.x, newD.y, newD.z, INFINITY);                // TMax = inf, :224
-        }
-        if (toFresh) store_path(qout, seg + (segCap - 1u - sf), p);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
     }
-
-    // ---- fresh paths: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
-    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
+    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {                // fresh entries
         const uint32_t local = tile * 256u + threadIdx.x;
         bool toTraced = false, toFresh = false;
         PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
         if (local < nF) {
             p = load_path(qin, seg + (segCap - 1u - local));
-            const uint32_t pixel = p.pixel;
-            const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
-            float uu, vv;
-            const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
-            const v3 rayDir = primaryRay.d;
-            const float4 pos = ((const float4*)tx.Position)[pixel];
-            const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
-            const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
-            const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
-            const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
-            SurfaceHit h;
-            h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;                  // HitInfo.hlsli:67-79
-            h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
-            h.GeometricNormal = oct_decode(snorm16_to_f32(ge.x), snorm16_to_f32(ge.y));
-            h.ShadingNormal = V3(snorm16_to_f32(nr.x), snorm16_to_f32(nr.y), snorm16_to_f32(nr.z));
-            h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
-            const v3 emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));           // :119,197
-            const float metal = unorm8_to_f32(bcm.w);
-            const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
-            const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
-            BSDFSample bs;
-            bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
-            int lobe = 0;
-            const bool first = p.sample == 0;
-            if (scatter(gs, p, h, bs, emission, rayDir, newO, newD, lobe)) {
-                toTraced = true;
-                if (aux && first) aux[p.pixel].y = lobe == LOBE_DIFFUSE ? 1.0f : 0.0f;       // isDiffuse of the lobe sampled at bounce 0, :237
-            } else toFresh = end_sample(gs, tx, aux, p);
+            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
         }
-        uint32_t st, sf;
-        block_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], lds, st, sf);
-        if (toTraced) {
-            store_path(qout, seg + st, p);
-            qout.r0[seg + st] = make_float4(newO.x, newO.y, newO.z, 0.0f);
-            qout.r1[seg + st] = make_float4(newD.x, newD.y, newD.z, INFINITY);
-        }
-        if (toFresh) store_path(qout, seg + (segCap - 1u - sf), p);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
     }
 }
 
@@ -612,6 +624,75 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
         }
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+}
+
+// One whole round in ONE launch: a block traces the rays of its tile and shades the same entries right away -- the hit stays in
+// registers (no hit record through HBM, no second count read, no grid-wide drain between the two halves) -- then shades its
+// fresh tiles. Same device functions as k_extend2 / k_shade, so the arithmetic and the queue protocol are unchanged; the
+// frame needs spp * (Bounces + 1) + 1 launches instead of twice as many, which is what the launch-bound regimes (tail
+// rounds, 1/8-frame shards of the multi-GPU run) are made of.
+template <bool TEXTURED, bool LDS, bool FLAT>
+__global__ __launch_bounds__(256) void k_round(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, BlobView bv,
+                                               PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
+                                               DeviceCounters* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t lds[16];
+    constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
+    const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
+    const uint32_t seg = sq * segCap;
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
+
+    if (bq * 256u < nT) {                                        // block-uniform
+        int* ldsStack = (int*)smem;
+        BlobReader<LDS> blob;
+        if constexpr (LDS) {
+            f4v* dst = (f4v*)(smem + kFixed);
+            const uint32_t n16 = bv.bytes / 16u;
+            for (uint32_t k = threadIdx.x; k < n16; k += 256u) dst[k] = bv.base[k];
+            __syncthreads();
+            blob.p = (const PT_LDS_AS f4v*)(smem + kFixed);
+        } else {
+            blob.p = bv.base;
+        }
+        AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+        TraceStats st; st.nodes = 0; st.tris = 0;
+        for (uint32_t base = bq * 256u; base < nT; base += nbq * 256u) {
+            const uint32_t local = base + threadIdx.x;
+            const bool valid = local < nT;
+            const uint32_t i = seg + (valid ? local : base);
+            float4 o = qin.r0[i], d = qin.r1[i];
+            if (!valid) { o.w = 1.0f; d.w = 0.0f; }               // empty interval: hits nothing, but the lane still serves work items
+            Hit h;
+            if constexpr (FLAT) {
+                unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+                h = trace_closest_flat<false, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st);
+            } else {
+                uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
+                h = trace_closest_v2<false, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
+            }
+            bool toTraced = false, toFresh = false;
+            PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+            if (valid) {
+                p = load_path(qin, i);
+                shade_traced<TEXTURED>(sv, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
+                                       V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD);
+            }
+            emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+        }
+    }
+    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
+        const uint32_t local = tile * 256u + threadIdx.x;
+        bool toTraced = false, toFresh = false;
+        PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        if (local < nF) {
+            p = load_path(qin, seg + (segCap - 1u - local));
+            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
+        }
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+    }
 }
 
 template <bool STATS>
@@ -761,6 +842,29 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
     k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    {
+        const bool lds = c.blob.bytes <= kBlobLdsMax;
+        const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
+        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
+        // fused rounds: everything except the validation / statistics variants, which keep the two-kernel form
+        const uint32_t pairOnly = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+        if (!(c.debugFlags & pairOnly)) {
+            for (uint32_t r = 0; r <= rounds; r++) {
+                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
+                timing_begin(c, c.evRound, c.nRound);
+                #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(sv, fv, c.frameConstants, tx, c.blob, qin, qout, aux, segCap, cin, cout, c.counters)
+                #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)
+                #define PT_ROUND_L(T) do { if (lds) PT_ROUND_F(T, true); else PT_ROUND_F(T, false); } while (0)
+                if (c.heapHasTextures) PT_ROUND_L(true); else PT_ROUND_L(false);
+                #undef PT_ROUND_L
+                #undef PT_ROUND_F
+                #undef PT_ROUND
+                timing_end(c, c.evRound, c.nRound); c.nRound++;
+            }
+            return hipGetLastError();
+        }
+    }
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
@@ -824,12 +928,13 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     c.lastIterations = rounds + 1;
 
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
-    const bool graphable = c.stream != nullptr && !c.timing && c.debugFlags == 0 && !c.disableGraphs;
+    const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
+                           (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED)) == 0;   // counters / validation variants launch directly
     if (graphable) {
         std::string key;
         key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
         key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
-        key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser);
+        key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
         if (key != c.graphKey || !c.graphExec) {
             if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }
             c.graphKey.clear();

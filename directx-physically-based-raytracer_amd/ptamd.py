@@ -24,7 +24,7 @@ EXPORTS = [
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
-    "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_enable_kernel_timing", "pt_get_kernel_timing",
+    "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_enable_kernel_timing", "pt_get_kernel_timing", "pt_get_round_timing",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
         lib.pt_set_debug_flags.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_debug_read_mismatch.argtypes = [C.c_void_p, C.c_void_p]
         lib.pt_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        lib.pt_get_round_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         lib.pt_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _LIB = lib
@@ -179,7 +180,10 @@ class DeviceContext:
     def kernel_timing(self):
         e, s, ne, ns = C.c_float(), C.c_float(), C.c_uint32(), C.c_uint32()
         self.check(self.lib.pt_get_kernel_timing(self.handle, C.byref(e), C.byref(s), C.byref(ne), C.byref(ns)))
-        return {"extend_ms": e.value, "shade_ms": s.value, "extend_launches": ne.value, "shade_launches": ns.value}
+        r, nr = C.c_float(), C.c_uint32()
+        self.check(self.lib.pt_get_round_timing(self.handle, C.byref(r), C.byref(nr)))
+        return {"extend_ms": e.value, "shade_ms": s.value, "extend_launches": ne.value, "shade_launches": ns.value,
+                "round_ms": r.value, "round_launches": nr.value}
 
     def accel_stats(self):
         s = AccelStats()

@@ -313,6 +313,7 @@ int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_TRAVERSAL_STATS 0x1u
 #define PT_DEBUG_TRAVERSAL_V1   0x4u     /* bounce rays use the interleaved TLAS/BLAS traversal of k_gbuffer instead of the phase-aligned one */
 #define PT_DEBUG_TRAVERSAL_PHASED 0x8u  /* bounce rays: the TLAS-walking phase-aligned schedule even when the scene is small enough for the flat one */
+#define PT_DEBUG_UNFUSED_ROUNDS  0x10u    /* a round = k_shade + k_extend2 (two launches, hit records through HBM) instead of the fused k_round */
 #define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
@@ -322,6 +323,8 @@ int  pt_debug_read_mismatch(PtContext* ctx, float* out16);
  * issued after pt_enable_kernel_timing(ctx, 1); the getter synchronises and returns the sums since then. */
 int  pt_enable_kernel_timing(PtContext* ctx, int enable);
 int  pt_get_kernel_timing(PtContext* ctx, float* extend_ms, float* shade_ms, uint32_t* extend_launches, uint32_t* shade_launches);
+/* the same for the fused round kernel (the default form of a round: trace + shade in one launch) */
+int  pt_get_round_timing(PtContext* ctx, float* round_ms, uint32_t* round_launches);
 
 #ifdef __cplusplus
 }
