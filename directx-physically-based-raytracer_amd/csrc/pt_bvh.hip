@@ -432,7 +432,8 @@ __global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const 
     pad_box(l4, h4);
     t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = bases[i].x;
     t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = bases[i].y;
-    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t._pad[0] = t._pad[1] = 0;
+    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t.instanceID = inst[i].instanceID; t._pad = 0;
+    for (int k = 0; k < 12; k++) t.objectToWorld[k] = M[k];
     out[i] = t;
 }
 

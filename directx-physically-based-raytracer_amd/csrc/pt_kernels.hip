@@ -90,18 +90,49 @@ PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)     
 // vertex-buffer positions); normals from the vertex buffer through the descriptor heap.
 // TEXTURED = false (no texture descriptor exists in the heap): tangents, UVs and the TextureMapInfo half of
 // ObjectData are never fetched.
-template <bool TEXTURED>
-PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot, float bu, float bv, v3 rayDir, SurfaceHit& h)
+// What hit reconstruction needs from the acceleration structure: the instance's two transforms, its InstanceID and the
+// triangle packet. Two sources with identical contents: the TLAS / BLAS arrays (k_gbuffer, k_shade) or the compact scene
+// blob, which the fused round kernel already holds in LDS for small scenes (two dependent HBM round trips less per hit).
+struct HitGeometry { float M[12], W[12]; uint32_t instanceID; TriPacket tp; };
+
+PT_DEV HitGeometry load_hit_geometry(const SceneView& sv, uint32_t inst, uint32_t triSlot)
 {
     const InstanceRecord* ir = &sv.accel.instances[inst];
-    const TriPacket tp = ir->tris[triSlot];
+    HitGeometry g;
+    g.tp = ir->tris[triSlot];
+    g.instanceID = ir->instanceID;
+    #pragma unroll
+    for (int k = 0; k < 12; k++) { g.M[k] = ir->objectToWorld[k]; g.W[k] = ir->worldToObject[k]; }
+    return g;
+}
+
+template <bool LDS>
+PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView& bv, uint32_t inst, uint32_t triSlot)
+{
+    const uint32_t ia = bv.instOff16 + inst * kInst16;
+    const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b1 = blob.ld(ia + 4), mk = blob.ld(ia + 5);
+    const f4v m0 = blob.ld(ia + 6), m1 = blob.ld(ia + 7), m2 = blob.ld(ia + 8);
+    const uint32_t ta = bv.triOff16 + (__float_as_uint(b1.w) + triSlot) * kTri16;
+    const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+    HitGeometry g;
+    g.tp.a = make_float4(pa.x, pa.y, pa.z, pa.w); g.tp.b = make_float4(pb.x, pb.y, pb.z, pb.w); g.tp.c = make_float4(pc.x, pc.y, pc.z, pc.w);
+    g.instanceID = __float_as_uint(mk.z);
+    g.W[0] = w0.x; g.W[1] = w0.y; g.W[2] = w0.z; g.W[3] = w0.w; g.W[4] = w1.x; g.W[5] = w1.y; g.W[6] = w1.z; g.W[7] = w1.w;
+    g.W[8] = w2.x; g.W[9] = w2.y; g.W[10] = w2.z; g.W[11] = w2.w;
+    g.M[0] = m0.x; g.M[1] = m0.y; g.M[2] = m0.z; g.M[3] = m0.w; g.M[4] = m1.x; g.M[5] = m1.y; g.M[6] = m1.z; g.M[7] = m1.w;
+    g.M[8] = m2.x; g.M[9] = m2.y; g.M[10] = m2.z; g.M[11] = m2.w;
+    return g;
+}
+
+template <bool TEXTURED>
+PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t inst, float bu, float bv, v3 rayDir, SurfaceHit& h)
+{
+    const TriPacket& tp = hg.tp;
     const uint32_t geom = __float_as_uint(tp.a.w), prim = __float_as_uint(tp.b.w);
     h.InstanceIndex = inst;
-    h.ObjectIndex = ir->instanceID + geom;                 // RaytracingHelpers.hlsli:79
+    h.ObjectIndex = hg.instanceID + geom;                  // RaytracingHelpers.hlsli:79
     h.PrimitiveIndex = prim;
-    float M[12], W[12];
-    #pragma unroll
-    for (int k = 0; k < 12; k++) { M[k] = ir->objectToWorld[k]; W[k] = ir->worldToObject[k]; }
+    const float* M = hg.M; const float* W = hg.W;
     safe_triangle_spawn_point(V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), bu, bv, M, W,
                               h.ObjectPosition, h.Position, h.FlatNormal, h.PositionOffset);
     const PtObjectData* od = &sv.objects[h.ObjectIndex];
@@ -147,6 +178,12 @@ PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot
 }
 
 PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
+
+template <bool TEXTURED>
+PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot, float bu, float bv, v3 rayDir, SurfaceHit& h)
+{
+    reconstruct_hit<TEXTURED>(sv, load_hit_geometry(sv, inst, triSlot), inst, bu, bv, rayDir, h);
+}
 
 template <bool TEXTURED>
 PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
@@ -441,8 +478,17 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const
 
 // ---- the bodies of k_shade, shared with the fused round kernel k_round ----------------------------------------
 // A traced path at its hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304. hit = (instance, triangle slot, u, v).
-template <bool TEXTURED>
-PT_DEV void shade_traced(const SceneView& sv, const PtSceneData& sd, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
+struct GeometryFromAccel {                                   // hit geometry out of the TLAS / BLAS arrays
+    const SceneView& sv;
+    PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry(sv, inst, slot); }
+};
+template <bool LDS> struct GeometryFromBlob {                // ... out of the scene blob (LDS-resident when LDS)
+    const BlobReader<LDS>& blob; const BlobView& bv;
+    PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry<LDS>(blob, bv, inst, slot); }
+};
+
+template <bool TEXTURED, typename GEOMETRY>
+PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const PtSceneData& sd, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
                          PathRegs& p, uint4 hr, float hitT, v3 rayDir, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
 {
     bool goes = false; int lobe = 0;
@@ -451,7 +497,7 @@ PT_DEV void shade_traced(const SceneView& sv, const PtSceneData& sd, const PtGra
         p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
     } else {                                                 // :293-304
         SurfaceHit h;
-        reconstruct_hit<TEXTURED>(sv, hr.x, hr.y, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+        reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
         const PtMaterial m = surface_material<TEXTURED>(sv, h);
         BSDFSample bs;
         bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
@@ -529,7 +575,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
             p = load_path(qin, i);
             const uint4 hr = qin.hit[i];
             const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
-            shade_traced<TEXTURED>(sv, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
+            shade_traced<TEXTURED>(sv, GeometryFromAccel{ sv }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
     }
@@ -664,6 +710,8 @@ __global__ __launch_bounds__(256) void k_round(SceneView sv, FrameView fv, const
             const bool valid = local < nT;
             const uint32_t i = seg + (valid ? local : base);
             float4 o = qin.r0[i], d = qin.r1[i];
+            PathRegs p = load_path(qin, i);                       // issued before the traversal: its latency hides behind it (registers are
+                                                                  // plentiful here, the kernel's budget is set by the shading half)
             if (!valid) { o.w = 1.0f; d.w = 0.0f; }               // empty interval: hits nothing, but the lane still serves work items
             Hit h;
             if constexpr (FLAT) {
@@ -674,10 +722,9 @@ __global__ __launch_bounds__(256) void k_round(SceneView sv, FrameView fv, const
                 h = trace_closest_v2<false, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
             }
             bool toTraced = false, toFresh = false;
-            PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+            v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
             if (valid) {
-                p = load_path(qin, i);
-                shade_traced<TEXTURED>(sv, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
+                shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
                                        V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD);
             }
             emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);

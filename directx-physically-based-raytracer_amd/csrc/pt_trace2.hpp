@@ -22,13 +22,14 @@ namespace pt {
 typedef float f4v __attribute__((ext_vector_type(4)));
 #define PT_LDS_AS __attribute__((address_space(3)))
 
-struct alignas(16) InstanceT {        // 96 B = 6 x 16
+struct alignas(16) InstanceT {        // 144 B = 9 x 16
     float worldToObject[12];
     float boxLo[3]; uint32_t nodeBase;   // padded world AABB of the instance | BLAS root index in the blob node array
     float boxHi[3]; uint32_t triBase;    //                                   | first packet of the BLAS in the blob triangle array
-    uint32_t mask, triCount, _pad[2];
+    uint32_t mask, triCount, instanceID, _pad;
+    float objectToWorld[12];             // units 6..8: only the shading half of k_round reads them (hit reconstruction)
 };
-static_assert(sizeof(InstanceT) == 96, "layout");
+static_assert(sizeof(InstanceT) == 144, "layout");
 
 struct BlobView {
     const f4v* base;                   // device pointer to the blob
@@ -37,7 +38,7 @@ struct BlobView {
     uint32_t bytes;                    // whole blob
 };
 
-constexpr uint32_t kInst16 = 6;        // 16-byte units per instance record
+constexpr uint32_t kInst16 = 9;        // 16-byte units per instance record
 constexpr uint32_t kNode16 = 4;
 constexpr uint32_t kTri16 = 3;
 constexpr int kCandidates = 8;         // K: candidate instances gathered per phase A

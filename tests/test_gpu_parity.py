@@ -234,7 +234,8 @@ def test_lbvh_vs_device_brute_force_no_mismatch(gpu, ptamd, pkg):
 
 def test_traversal_schedules_agree(gpu, ptamd, pkg):
     """The three schedules of the bounce-ray traversal (flat instance scan with wave-compacted work items, phase-aligned TLAS
-    walk, interleaved TLAS/BLAS) share tri_test / is_better, so images and ray counts must be identical bit for bit."""
+    walk, interleaved TLAS/BLAS) share tri_test / is_better, and a round is either one fused launch (k_round) or the
+    k_shade + k_extend2 pair: images and ray counts must be identical bit for bit in every combination."""
     S = pkg.scenes
     W, H = 96, 64
     scenes = [S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True),       # 9 instances: quads, boxes and a 320-triangle sphere
@@ -243,7 +244,7 @@ def test_traversal_schedules_agree(gpu, ptamd, pkg):
     for scene in scenes:
         gs = S.graphics_settings(W, H, spp=3, bounces=7, frame_index=2)
         results = []
-        for flags in (0, 8, 4):                                                    # default, PT_DEBUG_TRAVERSAL_PHASED, PT_DEBUG_TRAVERSAL_V1
+        for flags in (0, 8, 4, 0x10, 0x18):           # default (fused round), _PHASED, _V1, _UNFUSED_ROUNDS, _UNFUSED_ROUNDS | _PHASED
             gpu.set_sharding(0, 1, 16)
             g = ptamd.Scene(gpu, scene)
             r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
