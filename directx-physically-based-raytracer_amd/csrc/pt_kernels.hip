@@ -196,29 +196,56 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
 // ---------------------------------------------------------------------------------------------
 // G-buffer (Shaders/GBufferGeneration.hlsl:116-232). One thread per local pixel, 16x16 tiles.
 // ---------------------------------------------------------------------------------------------
-template <bool STATS, bool TEXTURED>
+// MODE 0: interleaved TLAS/BLAS walk over the acceleration-structure arrays (any scene). MODE 1 / 2: the flat schedule of
+// pt_trace2.hpp over the scene blob (<= kFlatInstances instances), blob staged in LDS / read from memory.
+template <bool STATS, bool TEXTURED, int MODE>
 __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, uint32_t flags, PtTextures tx,
-                                                 DeviceCounters* counters)
+                                                 BlobView bv, DeviceCounters* counters)
 {
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), ly = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (x >= fv.width || ly >= fv.localRows) return;          // no barrier below: early exit is safe
-    const uint32_t y = global_row(fv, ly);
+    const bool valid = x < fv.width && ly < fv.localRows;
+    if (MODE == 0 && !valid) return;                           // no barrier below in this mode: early exit is safe
+    const uint32_t y = global_row(fv, valid ? ly : 0u);
     const size_t pi = (size_t)ly * fv.width + x;
 
     float4 Position = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
     float LinearDepth = INFINITY, NormalizedDepth = cam.IsNormalizedDepthReversed ? 0.0f : 1.0f;
     float u, v;
-    const RayDesc ray = generate_pinhole_ray(cam, x, y, fv.width, fv.height, u, v);
-    __shared__ int ldsStack[kLdsStackDepth * 256];
-    int spill[kStackSize - kLdsStackDepth];
-    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    const RayDesc ray = generate_pinhole_ray(cam, valid ? x : 0u, y, fv.width, fv.height, u, v);
     TraceStats st; st.nodes = 0; st.tris = 0;
-    const Hit hit = trace_closest<STATS>(sv.accel, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
+    Hit hit;
+    HitGeometry hg;
+    if constexpr (MODE == 0) {
+        __shared__ int ldsStack[kLdsStackDepth * 256];
+        int spill[kStackSize - kLdsStackDepth];
+        TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+        hit = trace_closest<STATS>(sv.accel, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
+        if (hit.inst != ~0u) hg = load_hit_geometry(sv, hit.inst, hit.slot);
+    } else {
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+        constexpr bool LDS = MODE == 1;
+        BlobReader<LDS> blob;
+        if constexpr (LDS) {
+            f4v* dst = (f4v*)(smem + kFlatLdsFixed);
+            const uint32_t n16 = bv.bytes / 16u;
+            for (uint32_t k = threadIdx.x; k < n16; k += 256u) dst[k] = bv.base[k];
+            __syncthreads();
+            blob.p = (const PT_LDS_AS f4v*)(smem + kFlatLdsFixed);
+        } else {
+            blob.p = bv.base;
+        }
+        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+        // pixels outside the frame carry an empty ray interval: they hit nothing but their lanes still serve work items
+        hit = trace_closest_flat<STATS, LDS>(blob, bv, alpha_context(sv), ray.o, ray.d, valid ? ray.tmin : 1.0f, valid ? ray.tmax : 0.0f,
+                                             (int*)smem, ldsWave, &st);
+        if (!valid) return;
+        if (hit.inst != ~0u) hg = load_hit_geometry<LDS>(blob, bv, hit.inst, hit.slot);
+    }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
 
     if (hit.inst != ~0u) {
         SurfaceHit h;
-        reconstruct_hit<TEXTURED>(sv, hit.inst, hit.slot, hit.u, hit.v, ray.d, h);
+        reconstruct_hit<TEXTURED>(sv, hg, hit.inst, hit.u, hit.v, ray.d, h);
         if (flags & PT_GB_Geometry) {
             Position = make_float4(h.Position.x, h.Position.y, h.Position.z, h.PositionOffset);
             float ex, ey;
@@ -841,13 +868,17 @@ hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, 
     if (fv.localRows == 0 || fv.width == 0) return hipSuccess;
     dim3 grid((fv.width + 15) / 16, (fv.localRows + 15) / 16);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
-    if (c.heapHasTextures) {
-        if (stats) k_gbuffer<true, true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
-        else k_gbuffer<false, true><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
-    } else {
-        if (stats) k_gbuffer<true, false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
-        else k_gbuffer<false, false><<<grid, 256, 0, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.counters);
-    }
+    const bool flat = c.blob.base && c.blob.instCount <= kFlatInstances &&
+                      !(c.debugFlags & (PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE));
+    const int mode = !flat ? 0 : (c.blob.bytes <= kBlobLdsMax ? 1 : 2);
+    const uint32_t smem = mode == 0 ? 0u : kFlatLdsFixed + (mode == 1 ? c.blob.bytes : 0u);
+    #define PT_GB(S, T, M) k_gbuffer<S, T, M><<<grid, 256, smem, c.stream>>>(sv, fv, c.camera, c.sceneData, flags, tx, c.blob, c.counters)
+    #define PT_GB_M(S, T) do { if (mode == 0) PT_GB(S, T, 0); else if (mode == 1) PT_GB(S, T, 1); else PT_GB(S, T, 2); } while (0)
+    #define PT_GB_T(S) do { if (c.heapHasTextures) PT_GB_M(S, true); else PT_GB_M(S, false); } while (0)
+    if (stats) PT_GB_T(true); else PT_GB_T(false);
+    #undef PT_GB_T
+    #undef PT_GB_M
+    #undef PT_GB
     k_count_primary<<<1, 1, 0, c.stream>>>(c.counters, (unsigned long long)fv.width * fv.localRows);
     return hipGetLastError();
 }
