@@ -80,7 +80,7 @@ def load_library():
         # torch bundles its own libamdhip64.so.7; import it first so libptamd.so binds to the SAME HIP
         # runtime (two runtimes in one process cannot both open the device, and tensors would not be shared)
         import torch  # noqa: F401
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("PTAMD_LIB_AB", LIB_PATH))      # PTAMD_LIB_AB: developer aid, A/B-compare two builds on one box
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [C.c_void_p]
         lib.pt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
