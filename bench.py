@@ -284,6 +284,19 @@ def main():
             "note": "HIP-event time summed over every launch of the timed steps (all frames in flight, so a launch shares the GPU with "
                     "the other lanes' kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
         }
+        # the bound that actually binds: VALU issue. Instruction count per frame from the committed PMC
+        # profile, issue peak = CUs x 4 SIMDs x clock / 4 cycles per wave64 instruction
+        try:
+            vj = json.load(open(tpath)).get(args.workload + "_valu")
+        except Exception:
+            vj = None
+        if vj:
+            props = torch.cuda.get_device_properties(device)
+            peak_issue = props.multi_processor_count * 4 * 2.4e9 / 4.0
+            issued = vj["wave_instructions_per_frame"] * (args.steps / elapsed)
+            result["roofline"]["valu_issue"] = {"wave_instructions_per_frame": vj["wave_instructions_per_frame"], "issued_per_s": issued,
+                                                 "peak_per_s": peak_issue, "frac": issued / peak_issue,
+                                                 "note": "SQ_INSTS_VALU from profiles/ x frames/s of this run; 2.4 GHz engine clock"}
         serial = {}
         for name, v in kernel_table(ks, serial_secondary).items():
             g = gbps(v["bytes"], v["ms"]); so = gbps(v["state_bytes"], v["ms"])
