@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
         if (hit.inst != ~0u) hg = load_hit_geometry<LDS>(blob, bv, hit.inst, hit.slot);
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&counters->primaryRays, (unsigned long long)fv.width * fv.localRows);
 
     if (hit.inst != ~0u) {
         SurfaceHit h;
@@ -389,10 +390,11 @@ PT_DEV void block_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counter
 // Per-frame constants (camera, scene data, settings) live in a device buffer written in stream order by
 // k_set_constants, not in kernel arguments: the frame's launch sequence can then be captured once into a
 // hipGraph and replayed for every frame (FrameIndex, jitter, ... change without touching the graph).
-__global__ void k_set_constants(FrameConstants v, FrameConstants* dst)
+__global__ void k_set_constants(FrameConstants v, FrameConstants* dst, uint32_t* queueCounts, uint32_t countWords)
 {
     const uint32_t* s = (const uint32_t*)&v; uint32_t* d = (uint32_t*)dst;
     for (uint32_t i = threadIdx.x; i < sizeof(FrameConstants) / 4; i += blockDim.x) d[i] = s[i];
+    for (uint32_t i = threadIdx.x; i < countWords; i += blockDim.x) queueCounts[i] = 0u;      // the per-round queue counters of this frame
 }
 
 // Queue regions. Every sub-queue segment holds two kinds of entries, grown from its two ends:
@@ -836,7 +838,6 @@ hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t cou
     return hipGetLastError();
 }
 
-__global__ void k_count_primary(DeviceCounters* counters, unsigned long long n) { atomicAdd(&counters->primaryRays, n); }
 
 // dst[y][x] <- gathered per-rank band buffers (PtSharding layout)
 struct RankOffsets { uint64_t v[64]; };              // by value in the kernel arguments: no allocation, no copy, no sync
@@ -879,7 +880,6 @@ hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, 
     #undef PT_GB_T
     #undef PT_GB_M
     #undef PT_GB
-    k_count_primary<<<1, 1, 0, c.stream>>>(c.counters, (unsigned long long)fv.width * fv.localRows);
     return hipGetLastError();
 }
 
@@ -910,12 +910,10 @@ static void timing_begin(Context& c, std::vector<hipEvent_t>& ev, uint32_t k)
 }
 static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if (c.timing) hipEventRecord(ev[2 * k + 1], c.stream); }
 
-// the launch sequence of one frame: counters reset, k_pt_init, then the shade / extend rounds
+// the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
     const uint32_t cstride = 2u * kSubQueues;                                  // traced + fresh counters per round
-    hipError_t e;
-    if ((e = hipMemsetAsync(c.queueCounts, 0, sizeof(uint32_t) * (rounds + 2) * cstride, c.stream)) != hipSuccess) return e;
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
     k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
@@ -999,7 +997,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         c.pixelAuxCapacity = npix;
     }
     FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
-    k_set_constants<<<1, 192, 0, c.stream>>>(fc, c.frameConstants);
+    k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * 2u * kSubQueues);
     // persistent grid, but never more blocks than the queue has tiles: surplus blocks only cost dispatch slots and LDS that
     // a concurrent frame's kernels (other streams) could use -- this matters for small shards (1/8 of a 1080p frame = 1013 tiles)
     const uint32_t grid = std::min(persistent_grid(c.device), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
