@@ -330,6 +330,38 @@ def test_full_size_properties_c2(gpu, ptamd, pkg):
     assert np.array_equal(SH.deinterleave(pieces, H, 16), a["Radiance"])
 
 
+def test_frames_in_flight_are_independent(gpu, ptamd, pkg):
+    """bench.py keeps three frames in flight: one context + HIP stream + hipGraph per lane. Lanes must not see each other:
+    every frame, rendered while two others run, equals the same frame rendered alone on the default context."""
+    import torch
+    S = pkg.scenes
+    W, H = 480, 272
+    scene = S.cornell_box(aspect=W / H, variant="ggx")
+    settings = [S.graphics_settings(W, H, spp=3, bounces=6, frame_index=f) for f in range(3)]
+    alone = [gpu_render(ptamd, gpu, scene, gs, W, H)[0]["Radiance"] for gs in settings]
+    lanes = []
+    for _ in range(3):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx = ptamd.DeviceContext(0, stream=stream.cuda_stream)
+            ctx.set_sharding(0, 1, 16)
+            sc = ptamd.Scene(ctx, scene)
+            lanes.append((stream, ctx, sc, ptamd.Renderer(ctx, sc, W, H)))
+        stream.synchronize()
+    try:
+        for it in range(4):                                       # graph capture on the first pass, replay afterwards
+            for k, (stream, ctx, sc, r) in enumerate(lanes):
+                with torch.cuda.stream(stream):
+                    r.render(settings[(k + it) % 3])
+            torch.cuda.synchronize()
+            for k, (stream, ctx, sc, r) in enumerate(lanes):
+                got = ptamd.textures_to_numpy(r.textures)["Radiance"]
+                assert np.array_equal(got, alone[(k + it) % 3]), (it, k)
+    finally:
+        for stream, ctx, sc, r in lanes:
+            ctx.close()
+
+
 def test_error_behaviour(ptamd, pkg):
     """status codes in place of the reference's exceptions (Source/RaytracingHelpers.ixx:83-88, ErrorHelpers.ixx)."""
     import ctypes as C
