@@ -104,13 +104,14 @@ __global__ void k_gather_tris(const TriPacket* __restrict__ src, const uint64_t*
     if (i < n) dst[i] = src[(uint32_t)(keys[i] & 0xFFFFFFFFull)];
 }
 
-// BLAS leaves: <= kLeafTris consecutive Morton-ordered triangles; leaf box from the exact vertices
+// BLAS leaves: <= blas_leaf_tris(ntris) consecutive Morton-ordered triangles; leaf box from the exact vertices
 __global__ void k_blas_leaves(const TriPacket* __restrict__ tris, const uint64_t* __restrict__ triKeys, uint32_t ntris, uint32_t nleaves,
                               uint64_t* __restrict__ leafKeys, float4* __restrict__ leafLo, float4* __restrict__ leafHi, int* __restrict__ leafRef)
 {
     uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaves) return;
-    uint32_t first = l * kLeafTris, count = min(kLeafTris, ntris - first);
+    const uint32_t leafTris = blas_leaf_tris(ntris);
+    uint32_t first = l * leafTris, count = min(leafTris, ntris - first);
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (uint32_t i = 0; i < count; i++) {
         TriPacket t = tris[first + i];
@@ -330,7 +331,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
     uint32_t ntris = 0;
     for (uint32_t g = 0; g < ngeoms; g++) ntris += geoms[g].IndexCount / 3;
     out.triCount = ntris;
-    out.leafCount = cdiv(ntris, kLeafTris);
+    out.leafCount = cdiv(ntris, blas_leaf_tris(ntris));
     out.nodeCount = out.leafCount > 1 ? out.leafCount - 1 : 1;
     TriPacket* unsorted = nullptr; float4* boxLo = nullptr; float4* boxHi = nullptr; uint32_t* bounds = nullptr;
     uint64_t* keys = nullptr; uint64_t* keysSorted = nullptr;

@@ -50,11 +50,29 @@ struct TraceStats { uint32_t nodes, tris; };
 constexpr int kEntryDone = 0x7FFFFFFF;
 constexpr int kEntryRestore = 0x7FFFFFFE;
 constexpr int kStackSize = 96;
-constexpr uint32_t kLeafTris = 4;            // triangles per BLAS leaf (count field is 3 bits: <= 8)
+// Triangles per BLAS leaf, a function of the BLAS size so that builder and traversal agree without storing it. Measured on
+// MI355X (Mrays/s with leaves of 4 / 3 / 2 / 1 triangles): Cornell C2 8.16 / 8.04 / 8.84 / 7.43 G, 250k-triangle C3
+// 486 / 521 / 576 / 790 M, 10k-instance C5 1071 / 1025 / 1199 / 1339 M. A software triangle test costs about as much as a
+// node test and Morton-ordered neighbours make loose 4-triangle boxes, so big meshes want one triangle per leaf; the tiny
+// BLASes of a Cornell-type scene want their quads as ONE leaf (entered directly, no node) and faces kept in pairs.
+#ifndef PT_LEAF_RULE
+#define PT_LEAF_RULE 0
+#endif
+__host__ __device__ inline uint32_t blas_leaf_tris(uint32_t triCount)
+{
+#if PT_LEAF_RULE == 0
+    return triCount <= 32u ? 2u : 1u;
+#elif PT_LEAF_RULE == 1
+    return triCount <= 2u ? 2u : 1u;
+#else
+    return 2u;
+#endif
+}
+__host__ __device__ inline bool blas_single_leaf(uint32_t triCount) { return triCount <= blas_leaf_tris(triCount); }
 
 // A tree of one leaf has no internal node worth a visit (its root node would list the same leaf twice): traversal
 // starts at the leaf itself. BLAS leaf 0 covers packets [0, triCount); the only TLAS leaf is instance 0.
-PT_DEV int blas_root_entry(uint32_t triCount) { return triCount <= kLeafTris ? ~(int)(triCount - 1u) : 0; }   // triCount >= 1
+PT_DEV int blas_root_entry(uint32_t triCount) { return blas_single_leaf(triCount) ? ~(int)(triCount - 1u) : 0; }   // triCount >= 1
 PT_DEV int tlas_root_entry(uint32_t instCount) { return instCount == 1u ? ~0 : 0; }                            // instCount >= 1
 
 // Per-ray constants of the watertight test. kz = dominant axis of the direction (c2: z, else c1: y, else x),

@@ -173,7 +173,7 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
 // ---------------------------------------------------------------------------------------------
 // Flat variant for scenes with at most kFlatInstances instances (every Cornell-type scene): no TLAS walk.
 //   scan     all lanes test the world boxes of ALL instances in the same (uniform) order -- broadcast loads, no stack, no
-//            divergence -- and keep two bit masks: meshes and single-leaf instances (<= kLeafTris triangles, e.g. a quad)
+//            divergence -- and keep two bit masks: meshes and single-leaf instances (blas_single_leaf: e.g. a quad)
 //   items    every set bit is a work item (ray, instance). The items of the whole wave -- meshes first, then quads -- are
 //            compacted into a list in LDS and lane j processes items j, j + 64, ...: not necessarily of its own ray. A ray
 //            that touches two boxes and a wall is served by three lanes at once, a ray that touches one wall lends its lane
@@ -210,7 +210,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
             const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
             const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), tmax));
             const uint32_t bit = (tn <= tf * 1.0000004f) ? (1u << x) : 0u;
-            if (ntri <= kLeafTris) quads |= bit; else meshes |= bit;        // uniform select
+            if (blas_single_leaf(ntri)) quads |= bit; else meshes |= bit;   // uniform select
         }
         if (STATS) stats->nodes += (bv.instCount + 1u) / 2u;                // two boxes = one node's worth of bytes
     }
