@@ -1,13 +1,15 @@
 // pt_kernels.hip -- the render kernels (gfx950): primary-ray G-buffer and the wavefront path tracer.
 //
 //   k_gbuffer   <- Shaders/GBufferGeneration.hlsl:116-232 (main) + CastRay, Shaders/RaytracingHelpers.hlsli:57-133
-//   k_pt_init / k_shade / k_extend  <- Shaders/Raytracing.hlsl:103-415 (RayGeneration, DEFAULT permutation,
-//                                      Denoiser::None, DI off), split into wavefront stages:
+//   k_round (and its two-kernel form k_pt_init / k_shade / k_extend2)  <- Shaders/Raytracing.hlsl:103-415 (RayGeneration,
+//                                      DEFAULT permutation, DI off), as wavefront rounds over a path queue:
+//        extend  : closest-hit traversal of every queued ray (CastRay's TraceRay part), schedules in pt_trace2.hpp
 //        shade   : material + BSDF sample + Russian roulette for the vertex a path sits on
 //                  (Raytracing.hlsl:241-364), emits the next ray, regenerates the pixel's next sample in
 //                  place when a path ends (RNG state carried over, Raytracing.hlsl:108,191), compacts the
 //                  survivors with wave64 ballot + prefix popcount into the output queue
-//        extend  : closest-hit traversal of every queued ray (CastRay's TraceRay part)
+//        k_round : both halves for one tile in one launch, the hit never leaves registers (the product path)
+//   k_visibility / k_bsdf_evaluate  <- the shadow-ray TraceRay and all-lobe BSDF evaluate of the direct-lighting bridge
 // MFMA is not used: there is no dense contraction on this path.
 #include "pt_internal.hpp"
 

@@ -1,7 +1,8 @@
-// pt_trace2.hpp -- phase-aligned two-level traversal over the compact scene blob (gfx950).
+// pt_trace2.hpp -- two-level traversal over the compact scene blob (gfx950): the phase-aligned schedule below and, further
+// down, the flat schedule with wave-compacted work items for scenes of at most kFlatInstances instances.
 //
 // Same closest-hit semantics and arithmetic as pt_trace.hpp (tri_test / commit are shared), different
-// schedule, designed for wave64 SIMD efficiency:
+// schedules, designed for wave64 SIMD efficiency. Phase-aligned:
 //   phase A  every lane walks the TLAS only and collects up to K candidate instances in LDS
 //   phase B  candidate k of every lane is processed in lock-step: world-box re-test against the current
 //            best t, ray transform + Woop setup (the expensive block runs once per round, not once per
