@@ -232,6 +232,61 @@ def test_lbvh_vs_device_brute_force_no_mismatch(gpu, ptamd, pkg):
         assert c.SecondaryRays > W * H and c.BvhMismatches == 0
 
 
+def test_edge_case_scenes_bit_identical_to_oracle(gpu, ptamd, oracle, pkg):
+    """Inputs a scene loader can hand over: no instances at all, hidden instances (InstanceMask 0, Scene.ixx:365-377),
+    mirrored and strongly non-uniform instance transforms (negative determinant: worldToObject, normals and the spawn
+    offset must all follow), zero-area and repeated triangles inside a mesh, one mesh node instanced many times."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 96, 64
+
+    def check(scene, spp=2, bounces=5):
+        gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=7)
+        out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        assert_gbuffer_identical(out, ref_gb)
+        assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+        return out
+
+    # (a) nothing to hit: every pixel keeps the constant environment colour, no secondary ray is traced
+    cam = S.make_camera((0, 0, -2.0), hfov_deg=90.0, aspect=W / H)
+    empty = S.Scene([], [], cam, S.make_scene_data((0.25, 0.5, 0.75, 1.0)), name="empty").finalize()
+    out = check(empty)
+    rad16 = out["Radiance"].view(np.float16)[..., :3].astype(np.float32)          # primary misses keep what the G-buffer pass wrote
+    assert np.all(np.isinf(out["Position"][..., 3])) and np.allclose(rad16, (0.25, 0.5, 0.75))
+
+    # (b) hidden instances: the boxes and one wall are in the TLAS with mask 0
+    hidden = S.cornell_box(aspect=W / H, variant="ggx")
+    for k in (3, 6, 7):
+        hidden.objects[k].visible = False
+    hidden.finalize()
+    check(hidden)
+
+    # (c) mirrored (negative determinant) and 40:1 non-uniform instance transforms
+    odd = S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True)
+    odd.objects[6].transform = S.trs((-0.35, -0.4, 0.35), -18.0, (-0.6, 1.2, 0.6))
+    odd.objects[7].transform = S.trs((0.35, -0.9, -0.25), 15.0, (0.8, 0.02, 0.8))
+    odd.objects[8].transform = S.trs((0.3, -0.2, -0.3), 30.0, (0.25, -0.35, 0.15), pitch_deg=20.0)
+    odd.finalize()
+    check(odd)
+
+    # (d) degenerate geometry inside a mesh: a zero-area triangle, a collinear one and an exact duplicate of a real one
+    deg = S.cornell_box(aspect=W / H, variant="diffuse")
+    m = deg.nodes[6].meshes[0]
+    extra = np.array([0, 0, 0,  0, 1, 1,  0, 1, 2], m.indices.dtype)           # point, edge, copy of triangle 0
+    extra[6:9] = m.indices[0:3]
+    m.indices = np.concatenate([m.indices, extra])
+    deg.finalize()
+    check(deg)
+
+    # (e) one mesh node, many instances (same BLAS behind different transforms and InstanceIDs)
+    many = S.cornell_box(aspect=W / H, variant="ggx")
+    for k in range(10):
+        many.objects.append(S.RenderObject(7, S.trs((-0.8 + 0.17 * k, -0.9 + 0.08 * k, 0.6 - 0.1 * k), 13.0 * k, (0.12, 0.12, 0.12))))
+    many.finalize()
+    check(many)
+
+
 def test_traversal_schedules_agree(gpu, ptamd, pkg):
     """The three schedules of the bounce-ray traversal (flat instance scan with wave-compacted work items, phase-aligned TLAS
     walk, interleaved TLAS/BLAS) share tri_test / is_better, and a round is either one fused launch (k_round) or the
