@@ -708,8 +708,10 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
 // fresh tiles. Same device functions as k_extend2 / k_shade, so the arithmetic and the queue protocol are unchanged; the
 // frame needs spp * (Bounces + 1) + 1 launches instead of twice as many, which is what the launch-bound regimes (tail
 // rounds, 1/8-frame shards of the multi-GPU run) are made of.
+// 4 waves per SIMD = 128 VGPRs: fits without a spill (csrc/Makefile: -fno-slp-vectorize) and matches the 4 blocks per CU
+// the LDS footprint allows.
 template <bool TEXTURED, bool LDS, bool FLAT>
-__global__ __launch_bounds__(256) void k_round(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, BlobView bv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, BlobView bv,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
                                                DeviceCounters* counters)
 {
