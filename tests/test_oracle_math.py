@@ -224,3 +224,26 @@ def test_invert_3x4(oracle, pkg):
     M = np.vstack([m.reshape(3, 4), [0, 0, 0, 1]]).astype(np.float64)
     W = np.vstack([out.reshape(3, 4), [0, 0, 0, 1]]).astype(np.float64)
     assert np.allclose(M @ W, np.eye(4), atol=1e-6)
+
+
+def test_division_by_a_constant_through_double_is_the_ieee_fp32_quotient():
+    """csrc/pt_math.hpp PT_DIV_CONST: the kernels evaluate x / c for compile-time constants c (32767, 255, pi) as
+    (float)((double)x * (1.0 / (double)c)) -- 3 instructions instead of the ~10 of the fp32 division expansion. The
+    spec (and the oracle) say IEEE fp32 division; the two agree for every input: exhaustively for the integer cases the
+    texture / vertex decoders produce, and on 10^8 random floats (any sign, any exponent, denormal quotients) for pi."""
+    def mismatches(x, c):
+        x = x.astype(np.float32); c32 = np.float32(c)
+        with np.errstate(all="ignore"):
+            a = (x / c32).astype(np.float32)
+            b = (x.astype(np.float64) * (np.float64(1.0) / np.float64(c32))).astype(np.float32)
+        return int(((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).sum())
+    assert mismatches(np.arange(-32768, 32768), 32767.0) == 0          # SNORM16 decode (vertex normals, G-buffer normals)
+    assert mismatches(np.arange(0, 256), 255.0) == 0                   # UNORM8 decode
+    rng = np.random.default_rng(1)
+    pi32 = np.float32(3.14159265358979323846)
+    for _ in range(10):
+        bits = rng.integers(0, 2 ** 32, size=5_000_000, dtype=np.uint64).astype(np.uint32)
+        x = bits.view(np.float32)
+        assert mismatches(x[np.isfinite(x)], pi32) == 0
+    assert mismatches(rng.random(50_000_000).astype(np.float32) * 4, pi32) == 0
+    assert mismatches((rng.random(2_000_000) * 1e-37).astype(np.float32), pi32) == 0     # denormal quotients
