@@ -63,6 +63,90 @@ PT_DEV void node_test_v(f4v c0xy, f4v c1xy, f4v cz, v3 idir, v3 ood, float tmin,
     node_test(n, idir, ood, tmin, tmax, hit0, hit1, tn0, tn1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// A work item = (ray, instance): the unit the wave-compacted schedules below hand to whichever lane is free. The ray comes
+// out of the wave's LDS exchange area (rays[2 * lane] = o.xyz tmin, rays[2 * lane + 1] = d.xyz best t so far), the closest
+// hit inside the instance goes back as (t, u, v, slot); slot == ~0u: nothing closer than the ray's best t.
+// The item-local best starts at the ray's best t with an id that loses every tie, so a candidate at exactly that t is kept
+// and the ray's own lane applies the instance order when it merges.
+template <bool STATS, bool LDS, bool CULL, typename STACK>
+PT_DEV f4v trace_item(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, const f4v* rays, uint32_t src, uint32_t x,
+                      STACK& stack, TraceStats* stats)
+{
+    const f4v r0 = rays[2 * src], r1 = rays[2 * src + 1];
+    const v3 io = V3(r0.x, r0.y, r0.z), id = V3(r1.x, r1.y, r1.z);
+    const float itmin = r0.w, ibest = r1.w;
+    Hit hi; hi.t = ibest; hi.u = 0.0f; hi.v = 0.0f; hi.inst = 0xFFFFFFFEu; hi.geom = ~0u; hi.prim = ~0u; hi.slot = ~0u;
+    const uint32_t ia = bv.instOff16 + x * kInst16;
+    const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
+    bool enter = true;
+    if (CULL) {                      // late cull against the ray's best hit so far
+        const v3 iidir = safe_inv(id), iood = io * iidir;
+        const float lx = __builtin_fmaf(b0.x, iidir.x, -iood.x), hx = __builtin_fmaf(b1.x, iidir.x, -iood.x);
+        const float ly = __builtin_fmaf(b0.y, iidir.y, -iood.y), hy = __builtin_fmaf(b1.y, iidir.y, -iood.y);
+        const float lz = __builtin_fmaf(b0.z, iidir.z, -iood.z), hz = __builtin_fmaf(b1.z, iidir.z, -iood.z);
+        const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), itmin));
+        const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), ibest));
+        enter = tn <= tf * 1.0000004f;
+    }
+    if (enter) {
+        const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
+        const v3 ro = V3(w0.x * io.x + w0.y * io.y + w0.z * io.z + w0.w,
+                         w1.x * io.x + w1.y * io.y + w1.z * io.z + w1.w,
+                         w2.x * io.x + w2.y * io.y + w2.z * io.z + w2.w);
+        const v3 rd = V3(w0.x * id.x + w0.y * id.y + w0.z * id.z,
+                         w1.x * id.x + w1.y * id.y + w1.z * id.z,
+                         w2.x * id.x + w2.y * id.y + w2.z * id.z);
+        const RaySetup rs = ray_setup(rd);
+        const v3 bidir = safe_inv(rd), bood = ro * bidir;
+        const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+        const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
+        stack.push(kEntryRestore);
+        int c = blas_root_entry(__float_as_uint(blob.ld(ia + 5).y));      // single-leaf BLAS: straight to the leaf
+        while (true) {
+            while (c >= 0 && c < kEntryRestore) {
+                const uint32_t a = nodeBase + (uint32_t)c * kNode16;
+                const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
+                if (STATS) stats->nodes++;
+                bool h0, h1; float t0, t1;
+                node_test_v(n0, n1, n2, bidir, bood, itmin, hi.t, h0, h1, t0, t1);
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    int nearc = c0, farc = c1;
+                    if (t1 < t0) { nearc = c1; farc = c0; }
+                    stack.push(farc);
+                    c = nearc;
+                } else if (h0) c = c0;
+                else if (h1) c = c1;
+                else c = stack.pop();
+            }
+            if (c == kEntryRestore) break;
+            const uint32_t leaf = (uint32_t)~c;
+            const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t ta = triBase + (first + i) * kTri16;
+                const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+                if (STATS) stats->tris++;
+                float t, u, v;
+                if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
+                    commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
+            }
+            c = stack.pop();
+        }
+    }
+    return (f4v){ hi.t, hi.u, hi.v, __uint_as_float(hi.slot) };
+}
+
+// merge of one item result into the ray's best hit: is_better() with the instance as the whole tie-break (two results of a
+// ray never share an instance; geometry / primitive ties were settled inside the item)
+PT_DEV void merge_item(Hit& h, float tmin, f4v q, uint32_t x)
+{
+    const uint32_t slot = __float_as_uint(q.w);
+    if (slot != ~0u && q.x > tmin && (q.x < h.t || (q.x == h.t && h.inst != ~0u && x < h.inst))) {
+        h.t = q.x; h.u = q.y; h.v = q.z; h.inst = x; h.slot = slot;
+    }
+}
+
 // lane-private views of the LDS scratch: entry e of thread t at base[e * 256 + t]
 template <bool STATS, bool LDS, int STACK_DEPTH>
 PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
@@ -264,72 +348,9 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
         // ---- process: lane j takes items j, j + 64, ...
         for (uint32_t j = lane; j < total; j += 64u) {
             const uint32_t it = items[j];
-            const uint32_t src = it & 0xFFu, x = it >> 8;
-            const f4v r0 = rays[2 * src], r1 = rays[2 * src + 1];
-            const v3 io = V3(r0.x, r0.y, r0.z), id = V3(r1.x, r1.y, r1.z);
-            const float itmin = r0.w, ibest = r1.w;
-            // item-local best: starts at the ray's best t with an id that loses every tie, so a candidate at exactly that t
-            // is kept and the ray's own lane applies the instance order when it merges
-            Hit hi; hi.t = ibest; hi.u = 0.0f; hi.v = 0.0f; hi.inst = 0xFFFFFFFEu; hi.geom = ~0u; hi.prim = ~0u; hi.slot = ~0u;
-            const uint32_t ia = bv.instOff16 + x * kInst16;
-            const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
-            bool enter = true;
-            if (!firstBatch) {       // late cull against the best hit of earlier batches (the first starts from the scan's verdict)
-                const v3 iidir = safe_inv(id), iood = io * iidir;
-                const float lx = __builtin_fmaf(b0.x, iidir.x, -iood.x), hx = __builtin_fmaf(b1.x, iidir.x, -iood.x);
-                const float ly = __builtin_fmaf(b0.y, iidir.y, -iood.y), hy = __builtin_fmaf(b1.y, iidir.y, -iood.y);
-                const float lz = __builtin_fmaf(b0.z, iidir.z, -iood.z), hz = __builtin_fmaf(b1.z, iidir.z, -iood.z);
-                const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), itmin));
-                const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), ibest));
-                enter = tn <= tf * 1.0000004f;
-            }
-            if (enter) {
-                const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
-                const v3 ro = V3(w0.x * io.x + w0.y * io.y + w0.z * io.z + w0.w,
-                                 w1.x * io.x + w1.y * io.y + w1.z * io.z + w1.w,
-                                 w2.x * io.x + w2.y * io.y + w2.z * io.z + w2.w);
-                const v3 rd = V3(w0.x * id.x + w0.y * id.y + w0.z * id.z,
-                                 w1.x * id.x + w1.y * id.y + w1.z * id.z,
-                                 w2.x * id.x + w2.y * id.y + w2.z * id.z);
-                const RaySetup rs = ray_setup(rd);
-                const v3 bidir = safe_inv(rd), bood = ro * bidir;
-                const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-                const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-                stack.sp = 0;
-                stack.push(kEntryRestore);
-                int c = blas_root_entry(__float_as_uint(blob.ld(ia + 5).y));      // quads: straight to their only leaf
-                while (true) {
-                    while (c >= 0 && c < kEntryRestore) {
-                        const uint32_t a = nodeBase + (uint32_t)c * kNode16;
-                        const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
-                        if (STATS) stats->nodes++;
-                        bool h0, h1; float t0, t1;
-                        node_test_v(n0, n1, n2, bidir, bood, itmin, hi.t, h0, h1, t0, t1);
-                        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                        if (h0 && h1) {
-                            int nearc = c0, farc = c1;
-                            if (t1 < t0) { nearc = c1; farc = c0; }
-                            stack.push(farc);
-                            c = nearc;
-                        } else if (h0) c = c0;
-                        else if (h1) c = c1;
-                        else c = stack.pop();
-                    }
-                    if (c == kEntryRestore) break;
-                    const uint32_t leaf = (uint32_t)~c;
-                    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                    for (uint32_t i = 0; i < count; i++) {
-                        const uint32_t ta = triBase + (first + i) * kTri16;
-                        const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
-                        if (STATS) stats->tris++;
-                        float t, u, v;
-                        if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                            commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
-                    }
-                    c = stack.pop();
-                }
-            }
-            results[j] = (f4v){ hi.t, hi.u, hi.v, __uint_as_float(hi.slot) };                   // slot == ~0u: nothing committed
+            stack.sp = 0;
+            results[j] = firstBatch ? trace_item<STATS, LDS, false>(blob, bv, ac, rays, it & 0xFFu, it >> 8, stack, stats)      // first batch: the scan's verdict stands
+                                    : trace_item<STATS, LDS, true>(blob, bv, ac, rays, it & 0xFFu, it >> 8, stack, stats);
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -344,12 +365,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
                         uint32_t x;
                         if (pass == 0u) { x = (uint32_t)__builtin_ctz(meshes); meshes &= meshes - 1u; }
                         else { x = (uint32_t)__builtin_ctz(quads); quads &= quads - 1u; }
-                        const f4v q = results[off + (uint32_t)__builtin_popcountll(bb & ltMask)];
-                        const uint32_t slot = __float_as_uint(q.w);
-                        // is_better() with the instance as the whole tie-break: two results of a ray never share an instance
-                        if (slot != ~0u && q.x > tmin && (q.x < h.t || (q.x == h.t && h.inst != ~0u && x < h.inst))) {
-                            h.t = q.x; h.u = q.y; h.v = q.z; h.inst = x; h.slot = slot;
-                        }
+                        merge_item(h, tmin, results[off + (uint32_t)__builtin_popcountll(bb & ltMask)], x);
                     }
                     off += (uint32_t)__builtin_popcountll(bb);
                 }
