@@ -650,8 +650,9 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, AlphaContext
 
 // Traversal kernel (phase-aligned schedule, pt_trace2.hpp). Dynamic LDS: traversal stack (kStackLds entries
 // per lane) | candidate lists (kCandidates per lane) | the scene blob when it fits (LDS = true).
-constexpr int kStackLds2 = 16;
-constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u;
+constexpr int kStackLds2 = 10;                 // TLAS + BLAS share this stack in the phased schedule; deeper entries spill
+// phased schedule: stack | candidate lists | per-wave work-item exchange
+constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + 4u * kPhasedWaveLds;
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
 template <bool STATS, bool LDS, bool WRITE_T = false, bool FLAT = false>
@@ -692,12 +693,18 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
         }
     } else {
         uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
-        for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
-            const uint32_t i = sq * segCap + local;
-            const float4 o = q.r0[i], d = q.r1[i];
-            const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
-            q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
-            if (WRITE_T) q.r1[i].w = h.t;
+        unsigned char* ldsWave = smem + (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
+        for (uint32_t base = bq * 256u; base < n; base += nbq * 256u) {     // whole waves again: phase B trades work items
+            const uint32_t local = base + threadIdx.x;
+            const bool valid = local < n;
+            const uint32_t i = sq * segCap + (valid ? local : base);
+            float4 o = q.r0[i], d = q.r1[i];
+            if (!valid) { o.w = 1.0f; d.w = 0.0f; }
+            const Hit h = trace_closest_v2<STATS, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, ldsWave, &st);
+            if (valid) {
+                q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+                if (WRITE_T) q.r1[i].w = h.t;
+            }
         }
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
@@ -752,7 +759,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 h = trace_closest_flat<false, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st);
             } else {
                 uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
-                h = trace_closest_v2<false, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, &st);
+                unsigned char* ldsWave = smem + (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
+                h = trace_closest_v2<false, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, ldsWave, &st);
             }
             bool toTraced = false, toFresh = false;
             v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);

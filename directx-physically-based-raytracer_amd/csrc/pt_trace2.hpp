@@ -147,10 +147,16 @@ PT_DEV void merge_item(Hit& h, float tmin, f4v q, uint32_t x)
     }
 }
 
-// lane-private views of the LDS scratch: entry e of thread t at base[e * 256 + t]
+// Phase-aligned schedule. lane-private views of the LDS scratch: entry e of thread t at base[e * 256 + t].
+// Phase B hands the collected candidates to the wave as work items (trace_item): lanes with many candidates are helped by
+// lanes with few, instead of every lane waiting for the longest list (before: lock-step over candidate k of every lane).
+// The WHOLE wave must call this function (lanes without a ray pass an empty interval): its lanes trade work.
+constexpr uint32_t kPhasedItems = 128;                                       // items per batch and wave
+constexpr uint32_t kPhasedWaveLds = 64u * 32u + kPhasedItems * 16u + kPhasedItems * 4u;
+
 template <bool STATS, bool LDS, int STACK_DEPTH>
 PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                            int* ldsStack, uint32_t* ldsCand, TraceStats* stats)
+                            int* ldsStack, uint32_t* ldsCand, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     if (bv.instCount == 0) return h;
@@ -158,10 +164,16 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
     TraversalStack<STACK_DEPTH> stack; stack.init(ldsStack, spill);
     stack.push(kEntryDone);
     uint32_t* cand = ldsCand + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    f4v* rays = (f4v*)ldsWave;                                              // [lane][2]: o.xyz tmin | d.xyz best t
+    f4v* results = (f4v*)(ldsWave + 64u * 32u);                             // [item]: t u v slot
+    uint32_t* items = (uint32_t*)(ldsWave + 64u * 32u + kPhasedItems * 16u);  // [item]: lane | instance << 8
+    rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
 
     const v3 idir = safe_inv(d), ood = o * idir;
     int cur = tlas_root_entry(bv.instCount);
-    bool tlasDone = false;
+    bool tlasDone = !(tmin <= tmax);                                        // an empty interval (a lane without a ray) has nothing to walk
     while (true) {
         // ---------------- phase A: TLAS walk, collect candidates
         uint32_t nCand = 0;
@@ -184,72 +196,39 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
             } else if (cur == kEntryDone) {
                 tlasDone = true;
             } else {
-                cand[nCand * 256] = (uint32_t)~cur;
-                nCand++;
+                const uint32_t x = (uint32_t)~cur;
+                const f4v mk = blob.ld(bv.instOff16 + x * kInst16 + 5);      // mask, triCount, InstanceID, -
+                if ((__float_as_uint(mk.x) & 0xFFu) && __float_as_uint(mk.y) != 0u) { cand[nCand * 256] = x; nCand++; }
                 cur = stack.pop();
             }
         }
-        // ---------------- phase B: candidates in lock-step
-        for (uint32_t k = 0; k < nCand; k++) {
-            const uint32_t x = cand[k * 256];
-            const uint32_t ia = bv.instOff16 + x * kInst16;
-            const f4v b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);          // boxLo|nodeBase, boxHi|triBase
-            const f4v mk = blob.ld(ia + 5);                                  // mask, triCount, -, -
-            const uint32_t ntri = __float_as_uint(mk.y);
-            if (!(__float_as_uint(mk.x) & 0xFFu) || ntri == 0u) continue;
-            {   // late cull against the current best hit
-                const float lx = __builtin_fmaf(b0.x, idir.x, -ood.x), hx = __builtin_fmaf(b1.x, idir.x, -ood.x);
-                const float ly = __builtin_fmaf(b0.y, idir.y, -ood.y), hy = __builtin_fmaf(b1.y, idir.y, -ood.y);
-                const float lz = __builtin_fmaf(b0.z, idir.z, -ood.z), hz = __builtin_fmaf(b1.z, idir.z, -ood.z);
-                const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
-                const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), h.t));
-                if (!(tn <= tf * 1.0000004f)) continue;
-            }
-            const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
-            const v3 ro = V3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w,
-                             w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w,
-                             w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
-            const v3 rd = V3(w0.x * d.x + w0.y * d.y + w0.z * d.z,
-                             w1.x * d.x + w1.y * d.y + w1.z * d.z,
-                             w2.x * d.x + w2.y * d.y + w2.z * d.z);
-            const v3 bidir = safe_inv(rd), bood = ro * bidir;
-            const RaySetup rs = ray_setup(rd);
-            const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-            const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-            stack.push(kEntryRestore);
-            int c = blas_root_entry(ntri);
+        // ---------------- phase B: the wave's candidates as compacted work items, batch by batch
+        for (uint32_t k = 0; __ballot(nCand > k) != 0ull; ) {                // k: levels (k-th candidate of every lane) done; uniform
+            uint32_t total = 0, k2 = k;
             while (true) {
-                while (c >= 0 && c < kEntryRestore) {
-                    const uint32_t a = nodeBase + (uint32_t)c * kNode16;
-                    const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
-                    if (STATS) stats->nodes++;
-                    bool h0, h1; float t0, t1;
-                    node_test_v(n0, n1, n2, bidir, bood, tmin, h.t, h0, h1, t0, t1);
-                    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                    if (h0 && h1) {
-                        int nearc = c0, farc = c1;
-                        if (t1 < t0) { nearc = c1; farc = c0; }
-                        stack.push(farc);
-                        c = nearc;
-                    } else if (h0) c = c0;
-                    else if (h1) c = c1;
-                    else c = stack.pop();
-                }
-                if (c == kEntryRestore) break;
-                const uint32_t leaf = (uint32_t)~c;
-                const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-                for (uint32_t i = 0; i < count; i++) {
-                    const uint32_t ta = triBase + (first + i) * kTri16;
-                    const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
-                    if (STATS) stats->tris++;
-                    float t, u, v;
-                    if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                        commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
-                }
-                c = stack.pop();
+                const unsigned long long bb = __ballot(nCand > k2);
+                const uint32_t n = (uint32_t)__builtin_popcountll(bb);
+                if (n == 0u || total + n > kPhasedItems) break;
+                if (nCand > k2) items[total + (uint32_t)__builtin_popcountll(bb & ltMask)] = lane | (cand[k2 * 256] << 8);
+                total += n; k2++;
             }
+            rays[2 * lane + 1] = (f4v){ d.x, d.y, d.z, h.t };
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < total; j += 64u) {
+                const uint32_t it = items[j];
+                results[j] = trace_item<STATS, LDS, true>(blob, bv, ac, rays, it & 0xFFu, it >> 8, stack, stats);   // on top of this lane's TLAS stack
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t off = 0;
+            for (uint32_t kk = k; kk < k2; kk++) {
+                const unsigned long long bb = __ballot(nCand > kk);
+                if (nCand > kk) merge_item(h, tmin, results[off + (uint32_t)__builtin_popcountll(bb & ltMask)], cand[kk * 256]);
+                off += (uint32_t)__builtin_popcountll(bb);
+            }
+            __builtin_amdgcn_wave_barrier();
+            k = k2;
         }
-        if (tlasDone) break;
+        if (!__ballot(!tlasDone)) break;                                    // the wave leaves together: finished lanes keep serving items
     }
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;
