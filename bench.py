@@ -78,6 +78,32 @@ def cpu_baseline(scene, gs, W, H, L, budget_s=15.0):
             "sample": f"rows {y0}..{y1} of the {W}x{H} frame x{reps} ({rays} rays in {dt:.2f} s), oracle/pt_oracle.c with its own BVH, OpenMP"}
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with one rank per GPU; stdout of the children is scanned for the
+    JSON result line (rank 0 prints exactly one), everything else they print goes to our stderr."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC only on this pool (RCCL needs it across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in p.stdout:
+        if out.lstrip().startswith("{") and out.rstrip().endswith("}"):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +123,15 @@ def main():
                     help="developer aid: a round as two launches (k_shade + k_extend2) instead of the fused k_round, to profile the halves separately")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="developer aid for a 1-GPU box: run the N > 1 code path (RCCL process group, gather to rank 0, de-interleave) with world size 1")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="developer aid / CPU test: stop after the process group is up (gloo, no GPU touched) and print the world size")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves, as a CHILD process
+    # (never exec: nothing here has touched the GPU yet, and nothing may before this point), relay rank 0's one JSON line
+    # and leave with the child's return code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -106,8 +140,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world_size": dist.get_world_size(), "ranks_seen": int(t[0])}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     collective = world > 1 or args.rehearse_collective
@@ -217,6 +261,7 @@ def main():
             "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes),
                        "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
                        "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "rccl_world_size": dist.get_world_size() if collective else 1,
                        "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py)"},
         }
 
