@@ -24,22 +24,7 @@ static int fail_hip(Context* c, hipError_t e, const char* what)
 #define API_HIP(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); } while (0)
 #define API_ARG(ctx, cond, msg) do { if (!(cond)) return fail(ctx, PT_ERROR_INVALID_ARGUMENT, msg); } while (0)
 
-// worldToObject: inverse of the affine 3x4 evaluated in double, rounded once to float (DESIGN.md
-// "Arithmetic spec"; DXR derives CommittedWorldToObject3x4 inside the driver).
-static void invert_3x4(const float m[12], float out[12])
-{
-    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
-    double tx = m[3], ty = m[7], tz = m[11];
-    double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
-    double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
-    double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
-    double det = a * A + b * D + c * G;
-    double r = 1.0 / det;
-    double i00 = A * r, i01 = B * r, i02 = C * r, i10 = D * r, i11 = E * r, i12 = F * r, i20 = G * r, i21 = H * r, i22 = I * r;
-    out[0] = (float)i00; out[1] = (float)i01; out[2]  = (float)i02; out[3]  = (float)(-(i00 * tx + i01 * ty + i02 * tz));
-    out[4] = (float)i10; out[5] = (float)i11; out[6]  = (float)i12; out[7]  = (float)(-(i10 * tx + i11 * ty + i12 * tz));
-    out[8] = (float)i20; out[9] = (float)i21; out[10] = (float)i22; out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
-}
+static int poll_tlas_header(Context& c, bool wait);
 
 extern "C" {
 
@@ -63,8 +48,14 @@ int pt_create(int device_ordinal, PtContext** out_ctx)
     return PT_OK;
 }
 
-static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.rootBounds) hipFree(b.rootBounds); b = Blas(); }
-static void free_tlas(Tlas& t) { if (t.nodes) hipFree(t.nodes); if (t.instances) hipFree(t.instances); t = Tlas(); }
+static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
+static void free_tlas(Tlas& t)
+{
+    void* ptrs[] = { t.nodes, t.order, t.rootBounds, t.instances, (void*)t.blasBounds };
+    for (void* p : ptrs) if (p) hipFree(p);
+    t.tree.release();
+    t = Tlas();
+}
 
 void pt_destroy(PtContext* ctx)
 {
@@ -77,6 +68,10 @@ void pt_destroy(PtContext* ctx)
     if (c.heapDev) hipFree(c.heapDev);
     if (c.srgbLutDev) hipFree(c.srgbLutDev);
     if (c.blobDev) hipFree(c.blobDev);
+    if (c.tlasUploadDev) hipFree(c.tlasUploadDev);
+    if (c.tlasHeaderHost) hipHostFree(c.tlasHeaderHost);
+    if (c.tlasHeaderEvent) hipEventDestroy(c.tlasHeaderEvent);
+    if (c.validateDev) hipFree(c.validateDev);
     for (int k = 0; k < 2; k++) {
         PathQueue& q = c.queue[k];
         void* ptrs[6] = { q.s0, q.s1, q.s2, q.r0, q.r1, q.hit };
@@ -107,7 +102,7 @@ int pt_sync(PtContext* ctx)
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     API_HIP(&ctx->c, hipSetDevice(ctx->c.device));
     API_HIP(&ctx->c, hipStreamSynchronize(ctx->c.stream));
-    return PT_OK;
+    return poll_tlas_header(ctx->c, true);
 }
 
 // ---- descriptor heap ------------------------------------------------------------------------
@@ -163,17 +158,13 @@ static int upload_heap(Context& c)
     }
     if (n) API_HIP(&c, hipMemcpyAsync(c.heapDev, c.heapHost.data(), sizeof(HeapEntry) * n, hipMemcpyHostToDevice, c.stream));
     API_HIP(&c, hipStreamSynchronize(c.stream));     // heapHost may change right after
-    c.heapDirty = false;
+    c.heapDirty = false; c.validated = false;
     return PT_OK;
 }
 
 // ---- acceleration structures ----------------------------------------------------------------
-int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags, uint64_t* out_blas_id)
+static int check_geometries(Context& c, const PtGeometryDesc* geometries, uint32_t geometry_count)
 {
-    (void)build_flags;
-    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
-    Context& c = ctx->c;
-    API_ARG(&c, out_blas_id, "out_blas_id is NULL");
     API_ARG(&c, geometries || geometry_count == 0, "geometries is NULL");
     for (uint32_t g = 0; g < geometry_count; g++) {
         // same argument checks as CreateGeometryDesc, Source/RaytracingHelpers.ixx:82-89
@@ -182,39 +173,85 @@ int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint
         API_ARG(&c, geometries[g].IndexCount == 0 || (geometries[g].VertexBuffer && geometries[g].IndexBuffer), "geometry buffer is NULL");
         API_ARG(&c, geometries[g].VertexStride >= 12, "vertex stride must cover a float3 position");
     }
+    return PT_OK;
+}
+
+static void drop_tlas(Context& c) { c.haveTlas = false; c.tlasBlasIds.clear(); }
+
+// the traversal stack holds one entry per level of both trees plus the three of an instance transition (pt_trace.hpp)
+static int check_depth(Context& c, uint32_t tlasDepth)
+{
+    if (tlasDepth + c.maxBlasDepth + 4u > (uint32_t)kStackSize)
+        return fail(&c, PT_ERROR_INVALID_ARGUMENT, "acceleration structure too deep for the traversal stack (top level " + std::to_string(tlasDepth)
+                    + " + bottom level " + std::to_string(c.maxBlasDepth) + " levels)");
+    return PT_OK;
+}
+
+// the header of the last top-level build arrives asynchronously; look at it as soon as it is there
+static int poll_tlas_header(Context& c, bool wait)
+{
+    if (!c.tlasHeaderPending) return PT_OK;
+    if (wait) API_HIP(&c, hipEventSynchronize(c.tlasHeaderEvent));
+    else if (hipEventQuery(c.tlasHeaderEvent) != hipSuccess) { (void)hipGetLastError(); return PT_OK; }
+    c.tlasHeaderPending = false;
+    if (c.tlasHeaderHost->error) { drop_tlas(c); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "top-level build failed: tree deeper than the builder's level limit"); }
+    int s = check_depth(c, c.tlasHeaderHost->depth);
+    if (s != PT_OK) drop_tlas(c);
+    return s;
+}
+
+int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags, uint64_t* out_blas_id)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_ARG(&c, out_blas_id, "out_blas_id is NULL");
+    int s = check_geometries(c, geometries, geometry_count);
+    if (s != PT_OK) return s;
     API_HIP(&c, hipSetDevice(c.device));
     Blas b;
-    hipError_t e = build_blas_device(geometries, geometry_count, c.stream, b);
+    hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0, c.stream, b);
     if (e != hipSuccess) { free_blas(b); return fail_hip(&c, e, "bottom-level build"); }
+    if (b.buildError || b.depth + 4u > (uint32_t)kStackSize) { free_blas(b); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level build failed: tree too deep for the traversal stack"); }
+    b.geometryCount = geometry_count;
     uint64_t id = c.nextBlasId++;
     c.blas[id] = b;
+    c.maxBlasDepth = std::max(c.maxBlasDepth, b.depth);
     *out_blas_id = id;
     return PT_OK;
 }
 
 int pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags)
 {
-    (void)build_flags;
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     Context& c = ctx->c;
     auto it = c.blas.find(blas_id);
     API_ARG(&c, it != c.blas.end(), "unknown bottom-level id");
-    API_ARG(&c, geometries || geometry_count == 0, "geometries is NULL");
-    for (uint32_t g = 0; g < geometry_count; g++) {
-        API_ARG(&c, geometries[g].IndexStride == 2 || geometries[g].IndexStride == 4, "Triangle index format must be either uint16 or uint32");
-        API_ARG(&c, geometries[g].IndexCount % 3 == 0, "Triangle index count must be divisible by 3");
-    }
+    int s = check_geometries(c, geometries, geometry_count);
+    if (s != PT_OK) return s;
     API_HIP(&c, hipSetDevice(c.device));
-    // PERFORM_UPDATE (Source/Scene.ixx:327-341, CommandList::UpdateAccelerationStructures): the skinned vertices moved.
-    // The LBVH is rebuilt (Morton order may change) under the same id; a device build of a skinned mesh is cheaper than
-    // keeping a stale topology. The TLAS must be rebuilt afterwards (pt_build_top_level), as the reference does.
+    Blas& b = it->second;
+    uint32_t ntris = 0;
+    for (uint32_t g = 0; g < geometry_count; g++) ntris += geometries[g].IndexCount / 3;
+    // PERFORM_UPDATE (Source/Scene.ixx:327-341, CommandList::UpdateAccelerationStructures): the skinned vertices moved, the
+    // topology did not. A structure built with ALLOW_UPDATE is refitted in place: packets, boxes, quantised nodes; nothing is
+    // allocated and nothing waits. The TLAS must be rebuilt afterwards (pt_build_top_level), as the reference does every frame.
+    if (b.updatable && ntris == b.triCount && geometry_count == b.geometryCount) {
+        hipError_t e = refit_blas_device(geometries, geometry_count, c.stream, b);
+        if (e != hipSuccess) return fail_hip(&c, e, "bottom-level update");
+        drop_tlas(c);                                    // instance boxes are stale until the top level is rebuilt
+        return PT_OK;
+    }
+    // not built for updates, or a different triangle count: D3D12 would reject PERFORM_UPDATE; here the structure is rebuilt under its id
     API_HIP(&c, hipStreamSynchronize(c.stream));
-    Blas b;
-    hipError_t e = build_blas_device(geometries, geometry_count, c.stream, b);
-    if (e != hipSuccess) { free_blas(b); return fail_hip(&c, e, "bottom-level update"); }
-    free_blas(it->second);
-    it->second = b;
-    c.haveTlas = false;                                  // instance records point at the freed BLAS
+    Blas nb;
+    hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0 || b.updatable, c.stream, nb);
+    if (e != hipSuccess) { free_blas(nb); return fail_hip(&c, e, "bottom-level update"); }
+    if (nb.buildError || nb.depth + 4u > (uint32_t)kStackSize) { free_blas(nb); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level update failed: tree too deep for the traversal stack"); }
+    nb.geometryCount = geometry_count;
+    free_blas(b);
+    b = nb;
+    c.maxBlasDepth = std::max(c.maxBlasDepth, nb.depth);
+    drop_tlas(c);                                        // instance records point at the freed arrays
     return PT_OK;
 }
 
@@ -235,8 +272,13 @@ int pt_release_bottom_level(PtContext* ctx, uint64_t blas_id)
     auto it = c.blas.find(blas_id);
     API_ARG(&c, it != c.blas.end(), "unknown bottom-level id");
     hipStreamSynchronize(c.stream);
+    // the live top level may refer to it (instance records hold its arrays): that top level dies with it, and a render
+    // before the next pt_build_top_level answers PT_ERROR_NOT_READY instead of reading freed memory
+    for (uint64_t id : c.tlasBlasIds) if (id == blas_id) { drop_tlas(c); break; }
     free_blas(it->second);
     c.blas.erase(it);
+    c.maxBlasDepth = 0;
+    for (auto& kv : c.blas) c.maxBlasDepth = std::max(c.maxBlasDepth, kv.second.depth);
     return PT_OK;
 }
 
@@ -247,48 +289,112 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     Context& c = ctx->c;
     API_ARG(&c, descs || count == 0, "descs is NULL");
     API_HIP(&c, hipSetDevice(c.device));
-    std::vector<InstanceRecord> rec(count ? count : 1);
-    std::vector<const float*> bounds(count ? count : 1);
-    std::vector<BlobPiece> pieces; std::vector<uint32_t> pieceOfInstance(count ? count : 1);
-    std::map<uint64_t, uint32_t> pieceOfBlas;
-    uint32_t blobNodes = count > 1 ? count - 1 : 1, blobTris = 0;       // TLAS nodes come first in the blob
-    uint64_t tris = 0;
+    int st = poll_tlas_header(c, false);
+    if (st != PT_OK) return st;
+
+    // ---- host side: resolve ids, lay the blob out: [InstanceT x count | nodes: TLAS (reserved), then one piece per referenced
+    // bottom level | triangle packets per piece | instance order list]
+    const uint32_t tlasNodeCap = wide_node_capacity(count);
+    std::vector<uint64_t> pieceIds;
+    std::map<uint64_t, uint32_t> pieceOf;
+    std::vector<BlasEntry> table;
+    uint32_t blobNodes = tlasNodeCap, blobTris = 0;
+    uint64_t tris = 0, objectEnd = 0;
+    const size_t srcBytes = sizeof(InstanceSource) * (size_t)count;
+    std::vector<uint8_t>& up = c.tlasUploadHost;
+    up.resize(srcBytes);
     for (uint32_t i = 0; i < count; i++) {
         auto it = c.blas.find(descs[i].AccelerationStructure);
         API_ARG(&c, it != c.blas.end(), "instance refers to an unknown bottom-level id");
-        InstanceRecord& r = rec[i];
-        memcpy(r.objectToWorld, descs[i].Transform, sizeof(float) * 12);
-        invert_3x4(descs[i].Transform, r.worldToObject);
-        r.nodes = it->second.nodes; r.tris = it->second.tris;
-        r.instanceID = descs[i].InstanceID & 0xFFFFFFu;
-        r.mask = descs[i].InstanceMask & 0xFFu;
-        r.triCount = it->second.triCount; r._pad = 0;
-        bounds[i] = it->second.rootBounds;
-        tris += it->second.triCount;
-        auto pb = pieceOfBlas.find(descs[i].AccelerationStructure);
-        if (pb == pieceOfBlas.end()) {
-            const Blas& b = it->second;
-            pieces.push_back(BlobPiece{ b.nodes, b.tris, b.nodeCount, b.triCount, blobNodes, blobTris });
+        const Blas& b = it->second;
+        auto pb = pieceOf.find(descs[i].AccelerationStructure);
+        if (pb == pieceOf.end()) {
+            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris });
             blobNodes += b.nodeCount; blobTris += b.triCount;
-            pb = pieceOfBlas.emplace(descs[i].AccelerationStructure, (uint32_t)pieces.size() - 1).first;
+            pieceIds.push_back(descs[i].AccelerationStructure);
+            pb = pieceOf.emplace(descs[i].AccelerationStructure, (uint32_t)table.size() - 1).first;
         }
-        pieceOfInstance[i] = pb->second;
+        InstanceSource src;
+        memcpy(src.transform, descs[i].Transform, sizeof(float) * 12);
+        src.instanceID = descs[i].InstanceID & 0xFFFFFFu; src.mask = descs[i].InstanceMask & 0xFFu; src.blasSlot = pb->second; src._pad = 0;
+        memcpy(up.data() + sizeof(InstanceSource) * (size_t)i, &src, sizeof src);
+        tris += b.triCount;
+        objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
     }
-    API_HIP(&c, hipStreamSynchronize(c.stream));      // nothing may still be traversing the old TLAS
-    free_tlas(c.tlas); c.haveTlas = false;
-    Tlas t;
-    const float** dBounds = nullptr;
-    hipError_t e = hipMalloc((void**)&t.instances, sizeof(InstanceRecord) * (count ? count : 1));
-    if (e == hipSuccess) e = hipMalloc((void**)&dBounds, sizeof(float*) * (count ? count : 1));
-    if (e == hipSuccess && count) e = hipMemcpy(t.instances, rec.data(), sizeof(InstanceRecord) * count, hipMemcpyHostToDevice);
-    if (e == hipSuccess && count) e = hipMemcpy(dBounds, bounds.data(), sizeof(float*) * count, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = build_tlas_device(t.instances, dBounds, count, c.stream, t);
-    if (c.blobDev) { hipFree(c.blobDev); c.blobDev = nullptr; c.blob = BlobView{}; }
-    if (e == hipSuccess) e = build_blob_device(t, dBounds, pieces, pieceOfInstance, c.stream, &c.blobDev, &c.blob);
-    if (dBounds) hipFree(dBounds);
-    if (e != hipSuccess) { free_tlas(t); return fail_hip(&c, e, "top-level build"); }
-    t.triangleCount = tris;
-    c.tlas = t; c.haveTlas = true;
+    const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
+    const size_t orderBytes = ((size_t)count * 4 + 15) / 16 * 16;
+    const size_t total = instBytes + nodeBytes + triBytes + orderBytes;
+    API_ARG(&c, total / 16 < 0xFFFFFFFFull, "scene too large for 32-bit blob addressing");
+
+    // ---- capacities: everything is grow-only, so the rebuild of an unchanged scene layout (a dynamic frame) allocates nothing and
+    // waits for nothing; growth waits for the stream first (kernels in flight may still read the old buffers)
+    const bool growth = count > c.tlas.capacity || !c.tlas.nodes || count > c.tlasInstanceCap || !c.tlas.instances || total > c.blobCapacity || !c.blobDev;
+    if (growth) API_HIP(&c, hipStreamSynchronize(c.stream));
+    drop_tlas(c);
+    if (count > c.tlasInstanceCap || !c.tlas.instances) {
+        if (c.tlas.instances) hipFree(c.tlas.instances);
+        if (c.tlas.blasBounds) hipFree((void*)c.tlas.blasBounds);
+        c.tlas.instances = nullptr; c.tlas.blasBounds = nullptr; c.tlasInstanceCap = 0;
+        API_HIP(&c, hipMalloc((void**)&c.tlas.instances, sizeof(InstanceRecord) * (count ? count : 1)));
+        API_HIP(&c, hipMalloc((void**)&c.tlas.blasBounds, sizeof(float*) * (count ? count : 1)));
+        c.tlasInstanceCap = count ? count : 1;
+    }
+    if (total > c.blobCapacity || !c.blobDev) {
+        if (c.blobDev) hipFree(c.blobDev);
+        c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{};
+        API_HIP(&c, hipMalloc(&c.blobDev, total ? total : 16));
+        c.blobCapacity = total ? total : 16;
+    }
+    if (!c.tlasHeaderHost) {
+        API_HIP(&c, hipHostMalloc((void**)&c.tlasHeaderHost, sizeof(WideHeader)));
+        API_HIP(&c, hipEventCreateWithFlags(&c.tlasHeaderEvent, hipEventDisableTiming));
+    }
+    uint8_t* blob = (uint8_t*)c.blobDev;
+
+    // ---- one upload: instance sources | bottom-level table | copy jobs
+    std::vector<BlobCopy> jobs;
+    const size_t tableOff = (srcBytes + 15) / 16 * 16, tableBytes = sizeof(BlasEntry) * table.size();
+    for (const BlasEntry& e : table) {
+        jobs.push_back(BlobCopy{ e.nodes, blob + instBytes + sizeof(WideNode) * (size_t)e.nodeBase, sizeof(WideNode) * (size_t)e.nodeCount / 16 });
+        if (e.triCount) jobs.push_back(BlobCopy{ e.tris, blob + instBytes + nodeBytes + sizeof(TriPacket) * (size_t)e.triBase, sizeof(TriPacket) * (size_t)e.triCount / 16 });
+    }
+    hipError_t e = build_tlas_prepare(c.tlas, count);          // node / order arrays of the TLAS (grow-only), known before the jobs that copy them
+    if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
+    jobs.push_back(BlobCopy{ c.tlas.nodes, blob + instBytes, sizeof(WideNode) * (size_t)tlasNodeCap / 16 });
+    if (count) jobs.push_back(BlobCopy{ c.tlas.order, blob + instBytes + nodeBytes + triBytes, orderBytes / 16 });
+    const size_t jobsOff = (tableOff + tableBytes + 15) / 16 * 16, jobsBytes = sizeof(BlobCopy) * jobs.size();
+    up.resize(jobsOff + jobsBytes);
+    if (tableBytes) memcpy(up.data() + tableOff, table.data(), tableBytes);
+    memcpy(up.data() + jobsOff, jobs.data(), jobsBytes);
+    if (up.size() > c.tlasUploadCap || !c.tlasUploadDev) {
+        if (!growth) API_HIP(&c, hipStreamSynchronize(c.stream));
+        if (c.tlasUploadDev) hipFree(c.tlasUploadDev);
+        c.tlasUploadDev = nullptr; c.tlasUploadCap = 0;
+        API_HIP(&c, hipMalloc(&c.tlasUploadDev, up.size() * 2));           // head room: a few more instances next frame do not reallocate
+        c.tlasUploadCap = up.size() * 2;
+    }
+    API_HIP(&c, hipMemcpyAsync(c.tlasUploadDev, up.data(), up.size(), hipMemcpyHostToDevice, c.stream));   // pageable source: staged before the call returns
+    const InstanceSource* dSrc = (const InstanceSource*)c.tlasUploadDev;
+    const BlasEntry* dTable = (const BlasEntry*)((const uint8_t*)c.tlasUploadDev + tableOff);
+    const BlobCopy* dJobs = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + jobsOff);
+
+    // ---- device side, all in stream order
+    e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.stream);
+    if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
+    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.blasBounds, dTable, count, (InstanceT*)blob, dJobs, (uint32_t)jobs.size(), c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipEventRecord(c.tlasHeaderEvent, c.stream);
+    if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
+    c.tlasHeaderPending = true;
+    c.blob.base = (const f4v*)blob;
+    c.blob.instOff16 = 0; c.blob.nodeOff16 = (uint32_t)(instBytes / 16); c.blob.triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
+    c.blob.orderOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
+    c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
+    c.tlas.triangleCount = tris;
+    c.tlasBlasIds = pieceIds;
+    c.tlasObjectEnd = objectEnd;
+    c.validated = false;
+    c.haveTlas = true;
     return PT_OK;
 }
 
@@ -296,13 +402,19 @@ int pt_get_accel_stats(PtContext* ctx, PtAccelStats* out)
 {
     if (!ctx || !out) return PT_ERROR_INVALID_ARGUMENT;
     Context& c = ctx->c;
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    int st = poll_tlas_header(c, true);
+    if (st != PT_OK) return st;
     memset(out, 0, sizeof *out);
     out->InstanceCount = c.tlas.instanceCount;
     out->BottomLevelCount = (uint32_t)c.blas.size();
     out->TriangleCount = c.tlas.triangleCount;
-    out->NodeSizeBytes = sizeof(BvhNode); out->TriangleSizeBytes = sizeof(TriPacket);
-    uint64_t nb = (uint64_t)c.tlas.nodeCount * sizeof(BvhNode), tb = 0;
-    for (auto& kv : c.blas) { nb += (uint64_t)kv.second.nodeCount * sizeof(BvhNode); tb += (uint64_t)kv.second.triCount * sizeof(TriPacket); }
+    out->NodeSizeBytes = sizeof(WideNode); out->TriangleSizeBytes = sizeof(TriPacket);
+    uint64_t nb = (uint64_t)wide_node_capacity(c.tlas.instanceCount) * sizeof(WideNode), tb = 0;
+    for (auto& kv : c.blas) { nb += (uint64_t)kv.second.nodeCount * sizeof(WideNode); tb += (uint64_t)kv.second.triCount * sizeof(TriPacket); out->MaxBottomLevelDepth = std::max(out->MaxBottomLevelDepth, kv.second.depth); }
+    out->BlobBytes = c.blob.bytes;
+    if (c.tlasHeaderHost && !c.tlasHeaderPending) out->TopLevelDepth = c.tlasHeaderHost->depth;
     out->NodeBytes = nb; out->TriangleBytes = tb;
     return PT_OK;
 }
@@ -371,14 +483,52 @@ int pt_deinterleave_bands(PtContext* ctx, void* dst_full, const void* gathered, 
 }
 
 // ---- operators ------------------------------------------------------------------------------
+// Scene inputs the kernels will index with: checked once per change of (TLAS, ObjectData binding, heap), never per frame.
+// The reference gets these guarantees from D3D12's descriptor heap; here a wrong index would be a wild device read.
+static int validate_scene(Context& c)
+{
+    if (c.validated && c.validatedObjects == c.objects && c.validatedObjectCount == c.objectCount) return PT_OK;
+    const uint32_t heapCount = (uint32_t)c.heapHost.size();
+    if (c.tlasObjectEnd > c.objectCount)
+        return fail(&c, PT_ERROR_INVALID_ARGUMENT, "InstanceID + geometry count of an instance reaches ObjectData[" + std::to_string(c.tlasObjectEnd - 1)
+                    + "] but only " + std::to_string(c.objectCount) + " objects are bound (pt_set_object_data)");
+    if (c.instanceData && c.instanceDataCount < c.tlas.instanceCount)
+        return fail(&c, PT_ERROR_INVALID_ARGUMENT, "InstanceData holds fewer records than the top level has instances");
+    if (c.objectCount) {
+        if (!c.validateDev) API_HIP(&c, hipMalloc((void**)&c.validateDev, sizeof(uint32_t) * 4));
+        API_HIP(&c, hipMemsetAsync(c.validateDev, 0, sizeof(uint32_t) * 4, c.stream));
+        API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev));
+        uint32_t r[4] = { 0, 0, 0, 0 };
+        API_HIP(&c, hipMemcpyAsync(r, c.validateDev, sizeof r, hipMemcpyDeviceToHost, c.stream));
+        API_HIP(&c, hipStreamSynchronize(c.stream));
+        if (r[0]) {
+            static const char* what[] = { "", "MeshDescriptors.Vertices", "MeshDescriptors.Indices", "MeshDescriptors.MotionVectors", "TextureMapInfo.Descriptor" };
+            return fail(&c, PT_ERROR_INVALID_ARGUMENT, std::string("ObjectData[") + std::to_string(r[1]) + "]." + what[r[0] < 5 ? r[0] : 0] + " = " + std::to_string(r[2])
+                        + (r[3] ? " is not the kind of descriptor that member needs" : " is beyond the descriptor heap (" + std::to_string(heapCount) + " descriptors)"));
+        }
+    }
+    c.validated = true; c.validatedObjects = c.objects; c.validatedObjectCount = c.objectCount;
+    return PT_OK;
+}
+
 static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv, FrameView& fv, bool needFrameInputs = true)
 {
+    int s = poll_tlas_header(c, false);
+    if (s != PT_OK) return s;
     if (!c.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "no top-level acceleration structure: call pt_build_top_level first");
     if (needFrameInputs && (!c.haveCamera || !c.haveSceneData)) return fail(&c, PT_ERROR_NOT_READY, "camera / scene data not set");
     if (!c.objects && c.tlas.instanceCount) return fail(&c, PT_ERROR_NOT_READY, "object data not set");
-    int s = upload_heap(c);
+    s = upload_heap(c);
     if (s != PT_OK) return s;
-    sv.accel.tlasNodes = c.tlas.nodes; sv.accel.instances = c.tlas.instances; sv.accel.instanceCount = c.tlas.instanceCount;
+    s = validate_scene(c);
+    if (s != PT_OK) return s;
+    if (needFrameInputs && c.sceneData.EnvironmentLightTextureDescriptor != ~0u) {
+        const uint32_t d = c.sceneData.EnvironmentLightTextureDescriptor;
+        API_ARG(&c, d < c.heapHost.size(), "SceneData.EnvironmentLightTextureDescriptor is beyond the descriptor heap");
+        API_ARG(&c, c.heapHost[d].kind == (c.sceneData.IsEnvironmentLightTextureCubeMap ? kKindTextureCube : kKindTexture2D),
+                "SceneData.EnvironmentLightTextureDescriptor is not the kind of texture IsEnvironmentLightTextureCubeMap says");
+    }
+    sv.accel.instances = c.tlas.instances; sv.accel.instanceCount = c.tlas.instanceCount;
     sv.objects = c.objects; sv.objectCount = c.objectCount;
     sv.instanceData = c.instanceData;
     sv.heap = c.heapDev; sv.heapCount = (uint32_t)c.heapHost.size();
@@ -476,6 +626,7 @@ int pt_get_counters(PtContext* ctx, PtCounters* out)
     out->NodesVisited = d.nodesVisited; out->TrianglesTested = d.trianglesTested;
     out->WavefrontIterations = c.lastIterations;
     out->BvhMismatches = d.mismatchCount;
+    out->StackOverflows = d.stackOverflows;
     return PT_OK;
 }
 
@@ -488,6 +639,43 @@ int pt_debug_read_mismatch(PtContext* ctx, float* out16)
     API_HIP(&c, hipMemcpyAsync(&d, c.counters, sizeof d, hipMemcpyDeviceToHost, c.stream));
     API_HIP(&c, hipStreamSynchronize(c.stream));
     memcpy(out16, d.mismatchRay, sizeof(float) * 16);
+    return PT_OK;
+}
+
+int pt_debug_download_blob(PtContext* ctx, void* host_dst, uint64_t capacity_bytes, PtBlobLayout* out_layout)
+{
+    if (!ctx || !out_layout) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    int st = poll_tlas_header(c, true);
+    if (st != PT_OK) return st;
+    if (!c.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "no top-level acceleration structure");
+    const BlobView& b = c.blob;
+    *out_layout = PtBlobLayout{ b.instOff16, b.nodeOff16, b.triOff16, b.orderOff16, b.instCount, b.nodeCount, b.triCount, b.bytes };
+    if (host_dst) {
+        API_ARG(&c, capacity_bytes >= b.bytes, "host buffer smaller than the blob");
+        API_HIP(&c, hipMemcpy(host_dst, b.base, b.bytes, hipMemcpyDeviceToHost));
+    }
+    return PT_OK;
+}
+
+int pt_debug_trace_ray(PtContext* ctx, const PtRayDesc* host_ray, uint32_t* host_log, uint32_t log_words)
+{
+    if (!ctx || !host_ray || !host_log) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c;
+    API_HIP(&c, hipSetDevice(c.device));
+    SceneView sv; FrameView fv; memset(&sv, 0, sizeof sv); memset(&fv, 0, sizeof fv);
+    int s = make_views(c, 1, 1, sv, fv, false);
+    if (s != PT_OK) return s;
+    uint32_t* dev = nullptr;
+    API_HIP(&c, hipMalloc((void**)&dev, sizeof(uint32_t) * (log_words ? log_words : 4)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(uint32_t) * log_words, c.stream);
+    if (e == hipSuccess) e = launch_debug_trace(c, sv, (const float*)host_ray, dev, log_words);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_log, dev, sizeof(uint32_t) * log_words, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    hipFree(dev);
+    if (e != hipSuccess) return fail_hip(&c, e, "debug trace");
     return PT_OK;
 }
 

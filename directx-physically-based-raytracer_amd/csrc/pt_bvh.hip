@@ -1,16 +1,22 @@
-// pt_bvh.hip -- on-device LBVH construction (gfx950).
+// pt_bvh.hip -- on-device construction of the compressed wide BVH (gfx950).
 //
 // Replaces what the reference delegates to the D3D12 driver through RTXMU:
-//   Scene::CreateAccelerationStructures   Source/Scene.ixx:286-380
+//   Scene::CreateAccelerationStructures   Source/Scene.ixx:286-380        (PREFER_FAST_TRACE for static meshes, :329)
 //   CreateGeometryDesc / BuildTopLevelAccelerationStructure   Source/RaytracingHelpers.ixx:28-105
-//   CommandList::BuildAccelerationStructures                  Source/CommandList.ixx:217-233
+//   CommandList::BuildAccelerationStructures / UpdateAccelerationStructures   Source/CommandList.ixx:217-241
 //
-// Pipeline (all kernels on the context stream, no host round trip):
-//   triangle packets + boxes + scene bounds  ->  30-bit Morton code of the box centre, made unique
-//   by appending the primitive index  ->  rocPRIM radix sort of the 64-bit keys  ->  packets
-//   gathered into Morton order, <= 4 consecutive triangles per leaf  ->  Karras 2012 hierarchy over
-//   the leaves  ->  bottom-up refit (one atomic arrival counter per internal node) that emits the
-//   final 64-byte two-box nodes.  The TLAS runs the same tree builder over instance boxes.
+// Pipeline (all kernels on the context stream):
+//   triangle packets + boxes + scene bounds  ->  63-bit Morton code of the box centre (21 bits per axis), primitive index as
+//   the sort payload  ->  rocPRIM radix sort of (key, index)  ->  leaves of 1..3 consecutive triangles, padded boxes  ->
+//   Karras 2012 binary hierarchy over the leaves (ties between equal keys broken by position)  ->  bottom-up boxes (one
+//   atomic arrival counter per internal node)  ->  COLLAPSE to 8-wide nodes: starting from a binary node, the child with the
+//   largest surface area is opened until eight children stand (the SAH-greedy collapse of Ylitie et al. 2017), children are
+//   dealt to the slots that make "slot xor ray octant" a front-to-back order, boxes are quantised to 8 bits outward  ->
+//   triangle packets scattered into node order (a node's leaf triangles are contiguous).
+// The TLAS runs the same builder over instance boxes; its "triangles" are entries of the instance order list.
+// A bottom level built with PT_BUILD_FLAG_ALLOW_UPDATE keeps the binary topology, the Morton order and the slot assignment,
+// so that an update (skinned mesh moved) is a true refit: packets rewritten in place, boxes bottom-up, nodes re-quantised --
+// no allocation, no sort, no synchronisation.
 #include "pt_internal.hpp"
 
 #include <cstring>
@@ -36,11 +42,12 @@ __device__ __forceinline__ uint32_t load_index(const void* ib, uint32_t stride, 
     return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
 }
 
-// one thread per triangle of one geometry: packet, box, centre; block-reduced scene bounds
+// one thread per triangle of one geometry: packet, box; block-reduced scene bounds. slotOfPrim == nullptr (build): the
+// packet goes to tris[triOffset + p] (primitive order, scattered later); else (refit) straight to its final slot.
 __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, const void* __restrict__ ib, uint32_t istride,
                             uint32_t nprims, uint32_t triOffset, uint32_t geomIndex, uint32_t flags,
-                            TriPacket* __restrict__ tris, float4* __restrict__ boxLo, float4* __restrict__ boxHi,
-                            uint32_t* __restrict__ bounds)
+                            TriPacket* __restrict__ tris, const uint32_t* __restrict__ slotOfPrim,
+                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ bounds)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -55,7 +62,7 @@ __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, co
         t.a = make_float4(v[0][0], v[0][1], v[0][2], __uint_as_float(geomIndex));
         t.b = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(p));
         t.c = make_float4(v[2][0], v[2][1], v[2][2], __uint_as_float(flags));
-        tris[triOffset + p] = t;
+        tris[slotOfPrim ? slotOfPrim[triOffset + p] : triOffset + p] = t;
         for (int a = 0; a < 3; a++) {
             lo[a] = fminf(fminf(v[0][a], v[1][a]), v[2][a]);
             hi[a] = fmaxf(fmaxf(v[0][a], v[1][a]), v[2][a]);
@@ -63,6 +70,7 @@ __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, co
         boxLo[triOffset + p] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         boxHi[triOffset + p] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
+    if (!bounds) return;
     // wave64 reduction, then one atomic per wave and component
     for (int a = 0; a < 3; a++) {
         float l = lo[a], h = hi[a];
@@ -71,17 +79,19 @@ __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, co
     }
 }
 
-__device__ __forceinline__ uint32_t expand10(uint32_t v)
+__device__ __forceinline__ uint64_t expand21(uint32_t v)      // 21 bits -> every third bit of 63
 {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
 
 __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
-                         const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys)
+                         const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ index)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -92,40 +102,45 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
     uint32_t q[3];
     for (int a = 0; a < 3; a++) {
         float f = ext[a] > 0.0f ? (c[a] - mn[a]) / ext[a] : 0.0f;
-        q[a] = (uint32_t)fminf(fmaxf(f * 1024.0f, 0.0f), 1023.0f);
+        f = f == f ? f : 0.0f;                                                  // an empty (inverted) box has no centre
+        q[a] = (uint32_t)fminf(fmaxf(f * 2097152.0f, 0.0f), 2097151.0f);
     }
-    uint32_t m = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
-    keys[i] = ((uint64_t)m << 32) | (uint64_t)i;
+    keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    index[i] = i;
 }
 
-__global__ void k_gather_tris(const TriPacket* __restrict__ src, const uint64_t* __restrict__ keys, uint32_t n, TriPacket* __restrict__ dst)
+// conservative padding so that a hit reported by the watertight triangle test is never culled by
+// fp32 rounding in the slab test
+__device__ __forceinline__ void pad_box(float4& lo, float4& hi)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[(uint32_t)(keys[i] & 0xFFFFFFFFull)];
+    float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
+    for (int a = 0; a < 3; a++) {
+        if (l[a] <= h[a]) {
+            float e = 1e-5f * fmaxf(fabsf(l[a]), fabsf(h[a])) + 1e-6f * (h[a] - l[a]) + 1e-30f;
+            l[a] -= e; h[a] += e;
+        }
+    }
+    lo = make_float4(l[0], l[1], l[2], 0.0f); hi = make_float4(h[0], h[1], h[2], 0.0f);
 }
 
-// BLAS leaves: <= blas_leaf_tris(ntris) consecutive Morton-ordered triangles; leaf box from the exact vertices
-__global__ void k_blas_leaves(const TriPacket* __restrict__ tris, const uint64_t* __restrict__ triKeys, uint32_t ntris, uint32_t nleaves,
-                              uint64_t* __restrict__ leafKeys, float4* __restrict__ leafLo, float4* __restrict__ leafHi, int* __restrict__ leafRef)
+// Leaves: leafSize consecutive entries of the sorted order (BLAS: triangles, TLAS: one instance); padded union box.
+__global__ void k_leaves(const uint64_t* __restrict__ keysSorted, const uint32_t* __restrict__ indexSorted, const float4* __restrict__ boxLo,
+                         const float4* __restrict__ boxHi, uint32_t nitems, uint32_t nleaves, uint32_t leafSize,
+                         uint64_t* __restrict__ leafKeys, float4* __restrict__ leafLo, float4* __restrict__ leafHi)
 {
     uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaves) return;
-    const uint32_t leafTris = blas_leaf_tris(ntris);
-    uint32_t first = l * leafTris, count = min(leafTris, ntris - first);
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    uint32_t first = l * leafSize, count = min(leafSize, nitems - first);
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
     for (uint32_t i = 0; i < count; i++) {
-        TriPacket t = tris[first + i];
-        const float vx[3] = { t.a.x, t.b.x, t.c.x }, vy[3] = { t.a.y, t.b.y, t.c.y }, vz[3] = { t.a.z, t.b.z, t.c.z };
-        for (int k = 0; k < 3; k++) {
-            lo[0] = fminf(lo[0], vx[k]); hi[0] = fmaxf(hi[0], vx[k]);
-            lo[1] = fminf(lo[1], vy[k]); hi[1] = fmaxf(hi[1], vy[k]);
-            lo[2] = fminf(lo[2], vz[k]); hi[2] = fmaxf(hi[2], vz[k]);
-        }
+        const uint32_t s = indexSorted[first + i];
+        const float4 a = boxLo[s], b = boxHi[s];
+        lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
+        hi.x = fmaxf(hi.x, b.x); hi.y = fmaxf(hi.y, b.y); hi.z = fmaxf(hi.z, b.z);
     }
-    leafKeys[l] = triKeys[first];
-    leafLo[l] = make_float4(lo[0], lo[1], lo[2], 0.0f);
-    leafHi[l] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-    leafRef[l] = ~(int)((first << 3) | (count - 1));
+    pad_box(lo, hi);
+    if (leafKeys) leafKeys[l] = keysSorted[first];
+    leafLo[l] = lo; leafHi[l] = hi;
 }
 
 // TLAS items: world box of each instance = its BLAS root box pushed through ObjectToWorld (8 corners)
@@ -156,23 +171,14 @@ __global__ void k_instance_boxes(const InstanceRecord* __restrict__ inst, const 
     }
 }
 
-__global__ void k_tlas_leaves(const uint64_t* __restrict__ keys, const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
-                              float4* __restrict__ leafLo, float4* __restrict__ leafHi, int* __restrict__ leafRef)
-{
-    uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= n) return;
-    uint32_t i = (uint32_t)(keys[l] & 0xFFFFFFFFull);
-    leafLo[l] = boxLo[i]; leafHi[l] = boxHi[i];
-    leafRef[l] = ~(int)i;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j)
 {
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long)(keys[i] ^ keys[j]));      // keys are unique
+    const uint64_t x = keys[i] ^ keys[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);      // equal keys: the positions break the tie (section 4 of the paper)
 }
 
 // internal node i in [0, n-1): children + parent links. child < 0 means leaf ~(leaf index).
@@ -205,43 +211,16 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
     if (i == 0) parentInternal[0] = -1;
 }
 
-// conservative padding so that a hit reported by the watertight triangle test is never culled by
-// fp32 rounding in the slab test
-__device__ __forceinline__ void pad_box(float4& lo, float4& hi)
-{
-    float l[3] = { lo.x, lo.y, lo.z }, h[3] = { hi.x, hi.y, hi.z };
-    for (int a = 0; a < 3; a++) {
-        if (l[a] <= h[a]) {
-            float e = 1e-5f * fmaxf(fabsf(l[a]), fabsf(h[a])) + 1e-6f * (h[a] - l[a]) + 1e-30f;
-            l[a] -= e; h[a] += e;
-        }
-    }
-    lo = make_float4(l[0], l[1], l[2], 0.0f); hi = make_float4(h[0], h[1], h[2], 0.0f);
-}
-
-__device__ __forceinline__ void write_node(BvhNode* node, float4 lo0, float4 hi0, int c0, float4 lo1, float4 hi1, int c1)
-{
-    BvhNode n;
-    n.c0xy = make_float4(lo0.x, hi0.x, lo0.y, hi0.y);
-    n.c1xy = make_float4(lo1.x, hi1.x, lo1.y, hi1.y);
-    n.cz = make_float4(lo0.z, hi0.z, lo1.z, hi1.z);
-    n.child = make_int4(c0, c1, 0, 0);
-    *node = n;
-}
-
-// one thread per leaf climbs towards the root; the second arrival at a node owns it.
-// nodeLo/nodeHi: box of each internal node (scratch). rootBounds: lo.xyz hi.xyz of the whole tree.
-__global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi, const int* __restrict__ leafRef,
+// Boxes of the binary nodes: one thread per leaf climbs towards the root; the second arrival at a node owns it.
+// rootBounds: lo.xyz hi.xyz of the whole tree.
+__global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi,
                         const int2* __restrict__ children, const int* __restrict__ parentInternal, const int* __restrict__ parentLeaf,
-                        float4* nodeLo, float4* nodeHi, uint32_t* arrival, BvhNode* nodes, float* rootBounds)
+                        float4* nodeLo, float4* nodeHi, uint32_t* arrival, float* rootBounds)
 {
     int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaves) return;
     if (nleaves == 1) {
-        float4 lo = leafLo[0], hi = leafHi[0];
-        pad_box(lo, hi);
-        float4 elo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), ehi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
-        write_node(&nodes[0], lo, hi, leafRef[0], elo, ehi, leafRef[0]);
+        const float4 lo = leafLo[0], hi = leafHi[0];
         rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z; rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
         return;
     }
@@ -250,15 +229,12 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
         __threadfence();                                    // publish what this thread wrote below `cur`
         if (atomicAdd(&arrival[cur], 1u) == 0u) return;      // first arrival: the sibling will finish the node
         __threadfence();                                    // acquire the sibling subtree's boxes
-        int2 ch = children[cur];
-        float4 lo0, hi0, lo1, hi1; int c0, c1;
-        if (ch.x < 0) { lo0 = leafLo[~ch.x]; hi0 = leafHi[~ch.x]; pad_box(lo0, hi0); c0 = leafRef[~ch.x]; }
-        else { lo0 = nodeLo[ch.x]; hi0 = nodeHi[ch.x]; c0 = ch.x; }
-        if (ch.y < 0) { lo1 = leafLo[~ch.y]; hi1 = leafHi[~ch.y]; pad_box(lo1, hi1); c1 = leafRef[~ch.y]; }
-        else { lo1 = nodeLo[ch.y]; hi1 = nodeHi[ch.y]; c1 = ch.y; }
-        write_node(&nodes[cur], lo0, hi0, c0, lo1, hi1, c1);
-        float4 lo = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
-        float4 hi = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
+        arrival[cur] = 0u;                                  // ready for the next refit
+        const int2 ch = children[cur];
+        const float4 lo0 = ch.x < 0 ? leafLo[~ch.x] : nodeLo[ch.x], hi0 = ch.x < 0 ? leafHi[~ch.x] : nodeHi[ch.x];
+        const float4 lo1 = ch.y < 0 ? leafLo[~ch.y] : nodeLo[ch.y], hi1 = ch.y < 0 ? leafHi[~ch.y] : nodeHi[ch.y];
+        const float4 lo = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
+        const float4 hi = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
         nodeLo[cur] = lo; nodeHi[cur] = hi;
         if (cur == 0) {
             rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z; rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
@@ -267,11 +243,225 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
     }
 }
 
-__global__ void k_empty_tree(BvhNode* nodes, float* rootBounds)
+// ---------------------------------------------------------------------------------------------
+// collapse to compressed 8-wide nodes
+// ---------------------------------------------------------------------------------------------
+constexpr int kEmptyRef = 0x7FFFFFFF;
+constexpr uint32_t kMaxWideLevels = 60;                  // a deeper tree cannot be traversed with kStackSize entries anyway
+
+__device__ __forceinline__ void ref_box(int r, const float4* leafLo, const float4* leafHi, const float4* nodeLo, const float4* nodeHi, float4& lo, float4& hi)
 {
-    float4 elo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), ehi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
-    write_node(&nodes[0], elo, ehi, kEntryDone, elo, ehi, kEntryDone);
-    rootBounds[0] = rootBounds[1] = rootBounds[2] = INFINITY; rootBounds[3] = rootBounds[4] = rootBounds[5] = -INFINITY;
+    if (r < 0) { lo = leafLo[~r]; hi = leafHi[~r]; } else { lo = nodeLo[r]; hi = nodeHi[r]; }
+}
+__device__ __forceinline__ float half_area(float4 lo, float4 hi)
+{
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a == a && dx >= 0.0f ? a : 0.0f;               // empty boxes (inverted, infinite) never attract the collapse
+}
+
+// Origin, per-axis power-of-two scale and the 8-bit child boxes of a node (paper, section 3.3): e = ceil(log2(extent / 255)),
+// q_lo = floor((lo - p) / 2^e), q_hi = ceil((hi - p) / 2^e), each checked against its decoded value so that the stored box
+// contains the child box whatever the roundings were. Slots with refs[s] == kEmptyRef (or an empty child box) get lo > hi.
+__device__ void quantise_node(WideNode& n, float4 nlo, float4 nhi, const float4* clo, const float4* chi, const int* refs)
+{
+    const float p[3] = { nlo.x, nlo.y, nlo.z }, ph[3] = { nhi.x, nhi.y, nhi.z };
+    uint32_t q[2][3][8];
+    uint32_t eb[3];
+    const bool valid = p[0] <= ph[0] && p[1] <= ph[1] && p[2] <= ph[2] && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])
+                       && isfinite(ph[0]) && isfinite(ph[1]) && isfinite(ph[2]);
+    for (int a = 0; a < 3; a++) {
+        const float ext = valid ? ph[a] - p[a] : 0.0f;
+        int e;
+        (void)frexpf(ext * (1.0f / 255.0f), &e);             // ext / 255 = m * 2^e with m in [0.5, 1): 2^e covers it
+        if (!(ext > 0.0f)) e = -126;
+        while (true) {
+            if (e < -126) e = -126;
+            const float scale = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+            bool ok = true;
+            for (int s = 0; s < 8; s++) {
+                const float cl = a == 0 ? clo[s].x : (a == 1 ? clo[s].y : clo[s].z), ch = a == 0 ? chi[s].x : (a == 1 ? chi[s].y : chi[s].z);
+                if (!valid || refs[s] == kEmptyRef || !(cl <= ch)) { q[0][a][s] = 255u; q[1][a][s] = 0u; continue; }
+                float fl = floorf((cl - p[a]) * inv), fh = ceilf((ch - p[a]) * inv);
+                fl = fminf(fmaxf(fl, 0.0f), 255.0f); fh = fmaxf(fh, 0.0f);
+                while (fl > 0.0f && p[a] + fl * scale > cl) fl -= 1.0f;
+                while (fh <= 255.0f && p[a] + fh * scale < ch) fh += 1.0f;
+                if (fh > 255.0f) { ok = false; break; }
+                q[0][a][s] = (uint32_t)fl; q[1][a][s] = (uint32_t)fh;
+            }
+            if (ok || e >= 127) break;
+            e++;
+        }
+        eb[a] = (uint32_t)(e + 127);
+    }
+    n.origin[0] = valid ? p[0] : 0.0f; n.origin[1] = valid ? p[1] : 0.0f; n.origin[2] = valid ? p[2] : 0.0f;
+    n.expImask = (n.expImask & 0xFF000000u) | eb[0] | (eb[1] << 8) | (eb[2] << 16);
+    uint32_t* dst[2][3] = { { n.qlox, n.qloy, n.qloz }, { n.qhix, n.qhiy, n.qhiz } };
+    for (int k = 0; k < 2; k++)
+        for (int a = 0; a < 3; a++)
+            for (int h = 0; h < 2; h++)
+                dst[k][a][h] = q[k][a][4 * h] | (q[k][a][4 * h + 1] << 8) | (q[k][a][4 * h + 2] << 16) | (q[k][a][4 * h + 3] << 24);
+}
+
+struct CollapseArgs {
+    const int2* children; const float4* nodeLo; const float4* nodeHi; const float4* leafLo; const float4* leafHi;
+    uint32_t nleaves, nitems, leafSize;
+    WideNode* nodes; uint32_t nodeCapacity;
+    int* binaryRootOf;                   // [nodeCapacity] the binary node a wide node was grown from (also the work queue)
+    int* slotRefs;                       // [nodeCapacity * 8] binary ref held by each slot (refit re-quantises from these)
+    uint32_t* leafDst;                   // [nleaves] first item of each leaf in node order
+    WideHeader* header;
+};
+
+// ONE workgroup walks the wide tree level by level (a node's children are allocated by its thread, the next level is the
+// range allocated meanwhile): no inter-workgroup protocol, a loop bound every wave reaches, and a build of 250 k triangles
+// still takes well under a millisecond of a load-time operation.
+__global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
+{
+    __shared__ uint32_t sBegin, sEnd, sNodes, sItems, sError;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { sBegin = 0; sEnd = 1; sNodes = 1; sItems = 0; sError = 0; A.binaryRootOf[0] = 0; }
+    __syncthreads();
+    if (A.nleaves <= 1) {                               // no internal node: traversal starts at the leaf itself, the node is a placeholder
+        if (tid == 0) {
+            WideNode n; memset(&n, 0, sizeof n);
+            const float4 e = make_float4(0, 0, 0, 0);
+            float4 cl[8], ch[8]; int refs[8];
+            for (int s = 0; s < 8; s++) { cl[s] = e; ch[s] = e; refs[s] = kEmptyRef; A.slotRefs[s] = kEmptyRef; }
+            quantise_node(n, e, e, cl, ch, refs);
+            A.nodes[0] = n;
+            if (A.nleaves == 1) A.leafDst[0] = 0;
+            A.header->nodeCount = 1; A.header->itemCount = A.nitems; A.header->depth = 0; A.header->error = 0;
+        }
+        return;
+    }
+    uint32_t level = 0;
+    for (; level < kMaxWideLevels; level++) {
+        const uint32_t begin = sBegin, end = sEnd;
+        if (begin >= end) break;
+        for (uint32_t w = begin + tid; w < end; w += blockDim.x) {
+            int refs[8]; float4 lo[8], hi[8];
+            const int root = A.binaryRootOf[w];
+            int n = 2;
+            { const int2 c = A.children[root]; refs[0] = c.x; refs[1] = c.y; }
+            ref_box(refs[0], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[0], hi[0]);
+            ref_box(refs[1], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[1], hi[1]);
+            while (n < 8) {                                              // open the internal child with the largest surface area
+                int best = -1; float bestA = -1.0f;
+                for (int k = 0; k < n; k++) {
+                    if (refs[k] < 0) continue;
+                    const float a = half_area(lo[k], hi[k]);
+                    if (a > bestA) { bestA = a; best = k; }
+                }
+                if (best < 0) break;
+                const int2 c = A.children[refs[best]];
+                refs[best] = c.x; ref_box(c.x, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[best], hi[best]);
+                refs[n] = c.y; ref_box(c.y, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[n], hi[n]);
+                n++;
+            }
+            // slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2,
+            // greedy instead of the auction: repeatedly the cheapest unassigned (child, slot) pair)
+            float4 nlo, nhi;
+            ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
+            const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
+            int slotOf[8], childAt[8];
+            for (int s = 0; s < 8; s++) { childAt[s] = -1; slotOf[s] = -1; }
+            for (int round = 0; round < n; round++) {
+                int bc = -1, bs = -1; float bcost = INFINITY;
+                for (int c = 0; c < n; c++) {
+                    if (slotOf[c] >= 0) continue;
+                    float dx = 0.5f * (lo[c].x + hi[c].x) - cx, dy = 0.5f * (lo[c].y + hi[c].y) - cy, dz = 0.5f * (lo[c].z + hi[c].z) - cz;
+                    if (!(dx == dx)) dx = 0.0f;
+                    if (!(dy == dy)) dy = 0.0f;
+                    if (!(dz == dz)) dz = 0.0f;
+                    for (int s = 0; s < 8; s++) {
+                        if (childAt[s] >= 0) continue;
+                        const float cost = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
+                        if (cost < bcost || bc < 0) { bcost = cost; bc = c; bs = s; }
+                    }
+                }
+                slotOf[bc] = bs; childAt[bs] = bc;
+            }
+            // children and triangles of this node, in slot order
+            uint32_t nInternal = 0, nItems = 0, imask = 0;
+            for (int s = 0; s < 8; s++) {
+                const int c = childAt[s];
+                if (c < 0) continue;
+                if (refs[c] >= 0) { nInternal++; imask |= 1u << s; }
+                else { const uint32_t first = (uint32_t)(~refs[c]) * A.leafSize; nItems += min(A.leafSize, A.nitems - first); }
+            }
+            const uint32_t childBase = nInternal ? atomicAdd(&sNodes, nInternal) : 0u;
+            const uint32_t itemBase = nItems ? atomicAdd(&sItems, nItems) : 0u;
+            WideNode node; memset(&node, 0, sizeof node);
+            node.childBase = childBase; node.triBase = itemBase; node.expImask = imask << 24;
+            float4 slo[8], shi[8]; int srefs[8];
+            uint32_t ci = 0, ti = 0; uint8_t meta[8];
+            for (int s = 0; s < 8; s++) {
+                const int c = childAt[s];
+                meta[s] = 0; srefs[s] = kEmptyRef; slo[s] = make_float4(0, 0, 0, 0); shi[s] = slo[s];
+                if (c < 0) continue;
+                srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
+                if (refs[c] >= 0) {
+                    if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else sError = 1;
+                    ci++;
+                    meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+                } else {
+                    const uint32_t leaf = (uint32_t)(~refs[c]), first = leaf * A.leafSize, cnt = min(A.leafSize, A.nitems - first);
+                    A.leafDst[leaf] = itemBase + ti;
+                    meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
+                    ti += cnt;
+                }
+                A.slotRefs[(size_t)w * 8 + s] = srefs[s];
+            }
+            for (int s = 0; s < 8; s++) if (childAt[s] < 0) A.slotRefs[(size_t)w * 8 + s] = kEmptyRef;
+            node.meta[0] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
+            node.meta[1] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
+            quantise_node(node, nlo, nhi, slo, shi, srefs);
+            A.nodes[w] = node;
+        }
+        __syncthreads();
+        if (tid == 0) { sBegin = end; sEnd = min(sNodes, A.nodeCapacity); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        A.header->nodeCount = min(sNodes, A.nodeCapacity); A.header->itemCount = sItems; A.header->depth = level;
+        A.header->error = (sError || sBegin < sEnd) ? 1u : 0u;       // capacity exceeded (impossible: <= one wide node per binary node) or too deep
+    }
+}
+
+// after a refit: new boxes into the existing wide nodes (topology, slots, child and triangle references stay)
+__global__ void k_requantise(uint32_t nodeCount, WideNode* nodes, const int* __restrict__ binaryRootOf, const int* __restrict__ slotRefs,
+                             const float4* __restrict__ leafLo, const float4* __restrict__ leafHi, const float4* __restrict__ nodeLo, const float4* __restrict__ nodeHi)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nodeCount) return;
+    WideNode n = nodes[w];
+    float4 nlo, nhi, clo[8], chi[8]; int refs[8];
+    ref_box(binaryRootOf[w], leafLo, leafHi, nodeLo, nodeHi, nlo, nhi);
+    for (int s = 0; s < 8; s++) {
+        refs[s] = slotRefs[(size_t)w * 8 + s];
+        clo[s] = make_float4(0, 0, 0, 0); chi[s] = clo[s];
+        if (refs[s] != kEmptyRef) ref_box(refs[s], leafLo, leafHi, nodeLo, nodeHi, clo[s], chi[s]);
+    }
+    quantise_node(n, nlo, nhi, clo, chi, refs);
+    nodes[w] = n;
+}
+
+// triangle packets from primitive order into node order; slotOfPrim remembers the way for refits
+__global__ void k_scatter_tris(const TriPacket* __restrict__ src, const uint32_t* __restrict__ indexSorted, const uint32_t* __restrict__ leafDst,
+                               uint32_t n, uint32_t leafSize, TriPacket* __restrict__ dst, uint32_t* __restrict__ slotOfPrim)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;          // position in Morton order
+    if (m >= n) return;
+    const uint32_t leaf = m / leafSize, slot = leafDst[leaf] + (m - leaf * leafSize), prim = indexSorted[m];
+    dst[slot] = src[prim];
+    if (slotOfPrim) slotOfPrim[prim] = slot;
+}
+
+__global__ void k_scatter_order(const uint32_t* __restrict__ indexSorted, const uint32_t* __restrict__ leafDst, uint32_t n, uint32_t* __restrict__ order)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < n) order[leafDst[l]] = indexSorted[l];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -279,139 +469,231 @@ __global__ void k_empty_tree(BvhNode* nodes, float* rootBounds)
 // ---------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-struct Scratch {                      // freed when the build's stream work has completed
-    std::vector<void*> ptrs;
-    hipError_t alloc(void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) ptrs.push_back(*p); return e; }
-};
-
 #define BVH_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { err = e_; goto fail; } } while (0)
 
-static hipError_t sort_keys(uint64_t* keysIn, uint64_t* keysOut, uint32_t n, hipStream_t stream, Scratch& sc)
+void TreeBuffers::release()
 {
-    size_t tmpBytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, tmpBytes, keysIn, keysOut, n, 0, 62, stream);
-    if (e != hipSuccess) return e;
-    void* tmp = nullptr;
-    e = sc.alloc(&tmp, tmpBytes);
-    if (e != hipSuccess) return e;
-    return rocprim::radix_sort_keys(tmp, tmpBytes, keysIn, keysOut, n, 0, 62, stream);
+    void* ptrs[] = { boxLo, boxHi, bounds, keys, keysSorted, index, indexSorted, sortTemp, leafKeys, leafLo, leafHi, children, parentInternal,
+                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header };
+    for (void* p : ptrs) if (p) hipFree(p);
+    *this = TreeBuffers();
 }
 
-// builds the tree over nleaves prepared leaves (sorted unique keys, boxes, refs)
-static hipError_t build_tree(uint32_t nleaves, const uint64_t* leafKeys, const float4* leafLo, const float4* leafHi, const int* leafRef,
-                             BvhNode* nodes, float* rootBounds, hipStream_t stream, Scratch& sc)
+// (re)allocates the build buffers for nitems items in leaves of leafSize; grow-only, so a rebuild of the same size allocates nothing
+static hipError_t ensure_tree_buffers(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, bool withPrimSlots)
+{
+    const uint32_t nleaves = cdiv(nitems, leafSize), nint = nleaves > 1 ? nleaves - 1 : 1, nwide = wide_node_capacity(nleaves);
+    if (b.header && nitems <= b.itemCapacity && nleaves <= b.leafCapacity && (!withPrimSlots || b.slotOfPrim)) return hipSuccess;
+    b.release();
+    hipError_t err = hipSuccess;
+    const size_t ni = nitems ? nitems : 1, nl = nleaves ? nleaves : 1;
+    size_t tmp = 0;
+    BVH_CHECK(hipMalloc((void**)&b.boxLo, sizeof(float4) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.boxHi, sizeof(float4) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.bounds, sizeof(uint32_t) * 8));
+    BVH_CHECK(hipMalloc((void**)&b.keys, sizeof(uint64_t) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.keysSorted, sizeof(uint64_t) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.index, sizeof(uint32_t) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.indexSorted, sizeof(uint32_t) * ni));
+    BVH_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, b.keys, b.keysSorted, b.index, b.indexSorted, ni, 0, 63, (hipStream_t)nullptr));
+    b.sortTempBytes = tmp;
+    BVH_CHECK(hipMalloc(&b.sortTemp, tmp ? tmp : 16));
+    BVH_CHECK(hipMalloc((void**)&b.leafKeys, sizeof(uint64_t) * nl));
+    BVH_CHECK(hipMalloc((void**)&b.leafLo, sizeof(float4) * nl));
+    BVH_CHECK(hipMalloc((void**)&b.leafHi, sizeof(float4) * nl));
+    BVH_CHECK(hipMalloc((void**)&b.children, sizeof(int2) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.parentInternal, sizeof(int) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.parentLeaf, sizeof(int) * nl));
+    BVH_CHECK(hipMalloc((void**)&b.nodeLo, sizeof(float4) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.nodeHi, sizeof(float4) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.arrival, sizeof(uint32_t) * nint));
+    BVH_CHECK(hipMemset(b.arrival, 0, sizeof(uint32_t) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.binaryRootOf, sizeof(int) * nwide));
+    BVH_CHECK(hipMalloc((void**)&b.slotRefs, sizeof(int) * 8 * nwide));
+    BVH_CHECK(hipMalloc((void**)&b.leafDst, sizeof(uint32_t) * nl));
+    if (withPrimSlots) BVH_CHECK(hipMalloc((void**)&b.slotOfPrim, sizeof(uint32_t) * ni));
+    BVH_CHECK(hipMalloc((void**)&b.header, sizeof(WideHeader)));
+    b.itemCapacity = (uint32_t)ni; b.leafCapacity = (uint32_t)nl;
+    return hipSuccess;
+fail:
+    b.release();
+    return err;
+}
+
+// items in b.boxLo/boxHi/bounds -> sorted -> binary tree -> wide nodes in `nodes` (capacity: wide_node_capacity(nleaves)); no sync
+static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, WideNode* nodes, float* rootBounds, hipStream_t stream)
 {
     hipError_t err = hipSuccess;
-    if (nleaves == 0) { k_empty_tree<<<1, 1, 0, stream>>>(nodes, rootBounds); return hipGetLastError(); }
-    uint32_t nint = nleaves > 1 ? nleaves - 1 : 1;
-    int2* children = nullptr; int* parentInternal = nullptr; int* parentLeaf = nullptr;
-    float4* nodeLo = nullptr; float4* nodeHi = nullptr; uint32_t* arrival = nullptr;
-    BVH_CHECK(sc.alloc((void**)&children, sizeof(int2) * nint));
-    BVH_CHECK(sc.alloc((void**)&parentInternal, sizeof(int) * nint));
-    BVH_CHECK(sc.alloc((void**)&parentLeaf, sizeof(int) * nleaves));
-    BVH_CHECK(sc.alloc((void**)&nodeLo, sizeof(float4) * nint));
-    BVH_CHECK(sc.alloc((void**)&nodeHi, sizeof(float4) * nint));
-    BVH_CHECK(sc.alloc((void**)&arrival, sizeof(uint32_t) * nint));
-    BVH_CHECK(hipMemsetAsync(arrival, 0, sizeof(uint32_t) * nint, stream));
-    if (nleaves > 1) {
-        k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(leafKeys, (int)nleaves, children, parentInternal, parentLeaf);
-        BVH_CHECK(hipGetLastError());
+    const uint32_t nleaves = cdiv(nitems, leafSize);
+    if (nitems) {
+        k_morton<<<cdiv(nitems, 256), 256, 0, stream>>>(b.boxLo, b.boxHi, nitems, b.bounds, b.keys, b.index);
+        size_t tmp = b.sortTempBytes;
+        BVH_CHECK(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.index, b.indexSorted, nitems, 0, 63, stream));
+        k_leaves<<<cdiv(nleaves, 256), 256, 0, stream>>>(b.keysSorted, b.indexSorted, b.boxLo, b.boxHi, nitems, nleaves, leafSize, b.leafKeys, b.leafLo, b.leafHi);
+        if (nleaves > 1) k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(b.leafKeys, (int)nleaves, b.children, b.parentInternal, b.parentLeaf);
+        k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, b.leafLo, b.leafHi, b.children, b.parentInternal, b.parentLeaf, b.nodeLo, b.nodeHi, b.arrival, rootBounds);
+    } else {
+        const float e[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        BVH_CHECK(hipMemcpyAsync(rootBounds, e, sizeof e, hipMemcpyHostToDevice, stream));
     }
-    k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, leafLo, leafHi, leafRef, children, parentInternal, parentLeaf,
-                                                    nodeLo, nodeHi, arrival, nodes, rootBounds);
+    {
+        CollapseArgs A;
+        A.children = b.children; A.nodeLo = b.nodeLo; A.nodeHi = b.nodeHi; A.leafLo = b.leafLo; A.leafHi = b.leafHi;
+        A.nleaves = nleaves; A.nitems = nitems; A.leafSize = leafSize; A.nodes = nodes; A.nodeCapacity = wide_node_capacity(nleaves);
+        A.binaryRootOf = b.binaryRootOf; A.slotRefs = b.slotRefs; A.leafDst = b.leafDst; A.header = b.header;
+        k_collapse<<<1, 1024, 0, stream>>>(A);
+    }
     BVH_CHECK(hipGetLastError());
 fail:
     return err;
 }
 
-hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& out)
+hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool allowUpdate, hipStream_t stream, Blas& out)
 {
     hipError_t err = hipSuccess;
-    Scratch sc;
     uint32_t ntris = 0;
     for (uint32_t g = 0; g < ngeoms; g++) ntris += geoms[g].IndexCount / 3;
+    const uint32_t leafSize = blas_leaf_tris(ntris);
     out.triCount = ntris;
-    out.leafCount = cdiv(ntris, blas_leaf_tris(ntris));
-    out.nodeCount = out.leafCount > 1 ? out.leafCount - 1 : 1;
-    TriPacket* unsorted = nullptr; float4* boxLo = nullptr; float4* boxHi = nullptr; uint32_t* bounds = nullptr;
-    uint64_t* keys = nullptr; uint64_t* keysSorted = nullptr;
-    uint64_t* leafKeys = nullptr; float4* leafLo = nullptr; float4* leafHi = nullptr; int* leafRef = nullptr;
-    BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(BvhNode) * out.nodeCount));
+    out.leafCount = cdiv(ntris, leafSize);
+    const uint32_t capacity = wide_node_capacity(out.leafCount);
+    TriPacket* unsorted = nullptr;
+    WideHeader hdr{};
+    BVH_CHECK(ensure_tree_buffers(out.tree, ntris, leafSize, true));
+    BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(WideNode) * capacity));
     BVH_CHECK(hipMalloc((void**)&out.tris, sizeof(TriPacket) * (ntris ? ntris : 1)));
     BVH_CHECK(hipMalloc((void**)&out.rootBounds, sizeof(float) * 8));
     if (ntris) {
-        BVH_CHECK(sc.alloc((void**)&unsorted, sizeof(TriPacket) * ntris));
-        BVH_CHECK(sc.alloc((void**)&boxLo, sizeof(float4) * ntris));
-        BVH_CHECK(sc.alloc((void**)&boxHi, sizeof(float4) * ntris));
-        BVH_CHECK(sc.alloc((void**)&bounds, sizeof(uint32_t) * 8));
-        BVH_CHECK(sc.alloc((void**)&keys, sizeof(uint64_t) * ntris));
-        BVH_CHECK(sc.alloc((void**)&keysSorted, sizeof(uint64_t) * ntris));
-        BVH_CHECK(sc.alloc((void**)&leafKeys, sizeof(uint64_t) * out.leafCount));
-        BVH_CHECK(sc.alloc((void**)&leafLo, sizeof(float4) * out.leafCount));
-        BVH_CHECK(sc.alloc((void**)&leafHi, sizeof(float4) * out.leafCount));
-        BVH_CHECK(sc.alloc((void**)&leafRef, sizeof(int) * out.leafCount));
-        k_init_bounds<<<1, 64, 0, stream>>>(bounds);
+        BVH_CHECK(hipMalloc((void**)&unsorted, sizeof(TriPacket) * ntris));
+        k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
         uint32_t off = 0;
         for (uint32_t g = 0; g < ngeoms; g++) {
             uint32_t np = geoms[g].IndexCount / 3;
             if (np) k_tri_setup<<<cdiv(np, 256), 256, 0, stream>>>((const uint8_t*)geoms[g].VertexBuffer, geoms[g].VertexStride,
                                                                    geoms[g].IndexBuffer, geoms[g].IndexStride, np, off, g, geoms[g].Flags,
-                                                                   unsorted, boxLo, boxHi, bounds);
+                                                                   unsorted, nullptr, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
             off += np;
         }
         BVH_CHECK(hipGetLastError());
-        k_morton<<<cdiv(ntris, 256), 256, 0, stream>>>(boxLo, boxHi, ntris, bounds, keys);
-        BVH_CHECK(sort_keys(keys, keysSorted, ntris, stream, sc));
-        k_gather_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, keysSorted, ntris, out.tris);
-        k_blas_leaves<<<cdiv(out.leafCount, 256), 256, 0, stream>>>(out.tris, keysSorted, ntris, out.leafCount, leafKeys, leafLo, leafHi, leafRef);
-        BVH_CHECK(hipGetLastError());
     }
-    BVH_CHECK(build_tree(out.leafCount, leafKeys, leafLo, leafHi, leafRef, out.nodes, out.rootBounds, stream, sc));
+    BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, out.nodes, out.rootBounds, stream));
+    if (ntris) k_scatter_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, out.tree.indexSorted, out.tree.leafDst, ntris, leafSize, out.tris, out.tree.slotOfPrim);
+    BVH_CHECK(hipMemcpyAsync(&hdr, out.tree.header, sizeof hdr, hipMemcpyDeviceToHost, stream));
     BVH_CHECK(hipStreamSynchronize(stream));     // build is a load-time operation (reference: CommandList::End after the BLAS build, Scene.ixx:184-188)
+    out.nodeCount = hdr.nodeCount; out.depth = hdr.depth; out.buildError = hdr.error != 0;
+    if ((size_t)hdr.nodeCount * 2 < capacity) {   // the collapse needed far fewer nodes than the worst case: give the rest back
+        WideNode* exact = nullptr;
+        BVH_CHECK(hipMalloc((void**)&exact, sizeof(WideNode) * hdr.nodeCount));
+        BVH_CHECK(hipMemcpy(exact, out.nodes, sizeof(WideNode) * hdr.nodeCount, hipMemcpyDeviceToDevice));
+        hipFree(out.nodes); out.nodes = exact;
+    }
+    out.updatable = allowUpdate;
+    if (!allowUpdate) out.tree.release();          // a static mesh never refits (Scene.ixx:329: no ALLOW_UPDATE)
 fail:
-    for (void* p : sc.ptrs) hipFree(p);
+    if (unsorted) hipFree(unsorted);
+    return err;
+}
+
+// PERFORM_UPDATE: same topology, same Morton order, same slots -- packets and boxes only. Nothing is allocated and nothing waits.
+hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& b)
+{
+    if (!b.triCount) return hipSuccess;
+    const uint32_t leafSize = blas_leaf_tris(b.triCount);
+    uint32_t off = 0;
+    for (uint32_t g = 0; g < ngeoms; g++) {
+        uint32_t np = geoms[g].IndexCount / 3;
+        if (np) k_tri_setup<<<cdiv(np, 256), 256, 0, stream>>>((const uint8_t*)geoms[g].VertexBuffer, geoms[g].VertexStride,
+                                                               geoms[g].IndexBuffer, geoms[g].IndexStride, np, off, g, geoms[g].Flags,
+                                                               b.tris, b.tree.slotOfPrim, b.tree.boxLo, b.tree.boxHi, nullptr);
+        off += np;
+    }
+    k_leaves<<<cdiv(b.leafCount, 256), 256, 0, stream>>>(nullptr, b.tree.indexSorted, b.tree.boxLo, b.tree.boxHi, b.triCount, b.leafCount, leafSize,
+                                                         nullptr, b.tree.leafLo, b.tree.leafHi);
+    k_refit<<<cdiv(b.leafCount, 256), 256, 0, stream>>>((int)b.leafCount, b.tree.leafLo, b.tree.leafHi, b.tree.children, b.tree.parentInternal,
+                                                        b.tree.parentLeaf, b.tree.nodeLo, b.tree.nodeHi, b.tree.arrival, b.rootBounds);
+    if (b.leafCount > 1)
+        k_requantise<<<cdiv(b.nodeCount, 256), 256, 0, stream>>>(b.nodeCount, b.nodes, b.tree.binaryRootOf, b.tree.slotRefs, b.tree.leafLo, b.tree.leafHi,
+                                                                 b.tree.nodeLo, b.tree.nodeHi);
+    return hipGetLastError();
+}
+
+// TLAS over n instances: nodes into out.nodes, instance order list into out.order. build_tlas_prepare sizes the arrays (grow-only:
+// a rebuild with no more instances than before allocates nothing); build_tlas_device only enqueues kernels -- no sync, no
+// allocation; the header (node count, depth) stays on the device until the caller reads it.
+hipError_t build_tlas_prepare(Tlas& out, uint32_t n)
+{
+    hipError_t err = hipSuccess;
+    BVH_CHECK(ensure_tree_buffers(out.tree, n, 1, false));
+    if (n > out.capacity || !out.nodes) {
+        if (out.nodes) hipFree(out.nodes);
+        if (out.order) hipFree(out.order);
+        if (out.rootBounds) hipFree(out.rootBounds);
+        out.nodes = nullptr; out.order = nullptr; out.rootBounds = nullptr; out.capacity = 0;
+        const uint32_t cap = n ? n : 1;
+        BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(WideNode) * wide_node_capacity(cap)));
+        BVH_CHECK(hipMalloc((void**)&out.order, sizeof(uint32_t) * ((cap + 3) / 4 * 4)));
+        BVH_CHECK(hipMalloc((void**)&out.rootBounds, sizeof(float) * 8));
+        out.capacity = cap;
+    }
+fail:
     return err;
 }
 
 hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out)
 {
     hipError_t err = hipSuccess;
-    Scratch sc;
     out.instanceCount = n;
-    out.nodeCount = n > 1 ? n - 1 : 1;
-    float4* boxLo = nullptr; float4* boxHi = nullptr; uint32_t* bounds = nullptr; uint64_t* keys = nullptr; uint64_t* keysSorted = nullptr;
-    float4* leafLo = nullptr; float4* leafHi = nullptr; int* leafRef = nullptr; float* rootBounds = nullptr;
-    BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(BvhNode) * out.nodeCount));
-    BVH_CHECK(sc.alloc((void**)&rootBounds, sizeof(float) * 8));
     if (n) {
-        BVH_CHECK(sc.alloc((void**)&boxLo, sizeof(float4) * n));
-        BVH_CHECK(sc.alloc((void**)&boxHi, sizeof(float4) * n));
-        BVH_CHECK(sc.alloc((void**)&bounds, sizeof(uint32_t) * 8));
-        BVH_CHECK(sc.alloc((void**)&keys, sizeof(uint64_t) * n));
-        BVH_CHECK(sc.alloc((void**)&keysSorted, sizeof(uint64_t) * n));
-        BVH_CHECK(sc.alloc((void**)&leafLo, sizeof(float4) * n));
-        BVH_CHECK(sc.alloc((void**)&leafHi, sizeof(float4) * n));
-        BVH_CHECK(sc.alloc((void**)&leafRef, sizeof(int) * n));
-        k_init_bounds<<<1, 64, 0, stream>>>(bounds);
-        k_instance_boxes<<<cdiv(n, 256), 256, 0, stream>>>(dInstances, dBlasBounds, n, boxLo, boxHi, bounds);
-        k_morton<<<cdiv(n, 256), 256, 0, stream>>>(boxLo, boxHi, n, bounds, keys);
-        BVH_CHECK(hipGetLastError());
-        BVH_CHECK(sort_keys(keys, keysSorted, n, stream, sc));
-        k_tlas_leaves<<<cdiv(n, 256), 256, 0, stream>>>(keysSorted, boxLo, boxHi, n, leafLo, leafHi, leafRef);
-        BVH_CHECK(hipGetLastError());
+        k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
+        k_instance_boxes<<<cdiv(n, 256), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
-    BVH_CHECK(build_tree(n, keysSorted, leafLo, leafHi, leafRef, out.nodes, rootBounds, stream, sc));
-    BVH_CHECK(hipStreamSynchronize(stream));
+    BVH_CHECK(build_wide_tree(out.tree, n, 1, out.nodes, out.rootBounds, stream));
+    if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
+    BVH_CHECK(hipGetLastError());
 fail:
-    for (void* p : sc.ptrs) hipFree(p);
     return err;
 }
 
 // ---------------------------------------------------------------------------------------------
-// compact traversal blob: [InstanceT | nodes (TLAS first) | triangle packets], see pt_trace2.hpp
+// instance records + compact traversal blob: [InstanceT | nodes (TLAS first) | triangle packets | order], see pt_trace2.hpp
 // ---------------------------------------------------------------------------------------------
+// worldToObject: inverse of the affine 3x4 evaluated in double, rounded once to float (DESIGN.md "Arithmetic spec"; DXR derives
+// CommittedWorldToObject3x4 inside the driver). IEEE double operations in a fixed order, no contraction: the same bits on the
+// host (pt_invert_3x4 for tests) and here.
+__host__ __device__ void invert_3x4(const float m[12], float out[12])
+{
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    double tx = m[3], ty = m[7], tz = m[11];
+    double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+    double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+    double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+    double det = a * A + b * D + c * G;
+    double r = 1.0 / det;
+    double i00 = A * r, i01 = B * r, i02 = C * r, i10 = D * r, i11 = E * r, i12 = F * r, i20 = G * r, i21 = H * r, i22 = I * r;
+    out[0] = (float)i00; out[1] = (float)i01; out[2]  = (float)i02; out[3]  = (float)(-(i00 * tx + i01 * ty + i02 * tz));
+    out[4] = (float)i10; out[5] = (float)i11; out[6]  = (float)i12; out[7]  = (float)(-(i10 * tx + i11 * ty + i12 * tz));
+    out[8] = (float)i20; out[9] = (float)i21; out[10] = (float)i22; out[11] = (float)(-(i20 * tx + i21 * ty + i22 * tz));
+}
+
+// D3D12_RAYTRACING_INSTANCE_DESC (as uploaded by BuildTopLevelAccelerationStructure, RaytracingHelpers.ixx:60-63) -> instance
+// records; the bottom-level table maps the id the host resolved to the arrays of that BLAS
+__global__ void k_instance_records(const InstanceSource* __restrict__ src, const BlasEntry* __restrict__ table, uint32_t n,
+                                   InstanceRecord* __restrict__ rec, const float** __restrict__ bounds)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const InstanceSource s = src[i];
+    const BlasEntry b = table[s.blasSlot];
+    InstanceRecord r;
+    for (int k = 0; k < 12; k++) r.objectToWorld[k] = s.transform[k];
+    invert_3x4(s.transform, r.worldToObject);
+    r.nodes = b.nodes; r.tris = b.tris; r.instanceID = s.instanceID; r.mask = s.mask; r.triCount = b.triCount; r.blasSlot = s.blasSlot;
+    rec[i] = r;
+    bounds[i] = b.rootBounds;
+}
+
 __global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const float* const* __restrict__ blasBounds,
-                                 const uint2* __restrict__ bases, uint32_t n, InstanceT* __restrict__ out)
+                                 const BlasEntry* __restrict__ table, uint32_t n, InstanceT* __restrict__ out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -431,44 +713,36 @@ __global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const 
     }
     float4 l4 = make_float4(lo[0], lo[1], lo[2], 0.0f), h4 = make_float4(hi[0], hi[1], hi[2], 0.0f);
     pad_box(l4, h4);
-    t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = bases[i].x;
-    t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = bases[i].y;
+    const BlasEntry e = table[inst[i].blasSlot];
+    t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = e.nodeBase;
+    t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = e.triBase;
     t.mask = inst[i].mask; t.triCount = inst[i].triCount; t.instanceID = inst[i].instanceID; t._pad = 0;
     for (int k = 0; k < 12; k++) t.objectToWorld[k] = M[k];
     out[i] = t;
 }
 
-hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, const std::vector<BlobPiece>& pieces,
-                             const std::vector<uint32_t>& pieceOfInstance, hipStream_t stream, void** outDev, BlobView* outView)
+// one block per copy job: BLAS nodes / packets and the TLAS pieces into their blob sections (device-to-device, 16 B per lane)
+__global__ __launch_bounds__(256) void k_blob_copy(const BlobCopy* __restrict__ jobs, uint32_t njobs)
 {
-    hipError_t err = hipSuccess;
-    const uint32_t n = tlas.instanceCount;
-    uint32_t nodeCount = tlas.nodeCount, triCount = 0;
-    for (const BlobPiece& p : pieces) { nodeCount += p.nodeCount; triCount += p.triCount; }
-    const size_t instBytes = (size_t)n * sizeof(InstanceT), nodeBytes = (size_t)nodeCount * sizeof(BvhNode), triBytes = (size_t)triCount * sizeof(TriPacket);
-    const size_t total = instBytes + nodeBytes + triBytes;
-    uint8_t* blob = nullptr; uint2* dBases = nullptr;
-    std::vector<uint2> bases(n ? n : 1);
-    BVH_CHECK(hipMalloc((void**)&blob, total ? total : 16));
-    BVH_CHECK(hipMalloc((void**)&dBases, sizeof(uint2) * (n ? n : 1)));
-    for (uint32_t i = 0; i < n; i++) { const BlobPiece& p = pieces[pieceOfInstance[i]]; bases[i] = make_uint2(p.nodeBase, p.triBase); }
-    if (n) BVH_CHECK(hipMemcpyAsync(dBases, bases.data(), sizeof(uint2) * n, hipMemcpyHostToDevice, stream));
-    BVH_CHECK(hipMemcpyAsync(blob + instBytes, tlas.nodes, sizeof(BvhNode) * tlas.nodeCount, hipMemcpyDeviceToDevice, stream));
-    for (const BlobPiece& p : pieces) {
-        BVH_CHECK(hipMemcpyAsync(blob + instBytes + sizeof(BvhNode) * p.nodeBase, p.nodes, sizeof(BvhNode) * p.nodeCount, hipMemcpyDeviceToDevice, stream));
-        if (p.triCount) BVH_CHECK(hipMemcpyAsync(blob + instBytes + nodeBytes + sizeof(TriPacket) * p.triBase, p.tris, sizeof(TriPacket) * p.triCount, hipMemcpyDeviceToDevice, stream));
+    for (uint32_t j = blockIdx.y; j < njobs; j += gridDim.y) {
+        const BlobCopy c = jobs[j];
+        const uint4* s = (const uint4*)c.src; uint4* d = (uint4*)c.dst;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.n16; i += (uint64_t)gridDim.x * blockDim.x) d[i] = s[i];
     }
-    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(tlas.instances, dBlasBounds, dBases, n, (InstanceT*)blob);
-    BVH_CHECK(hipGetLastError());
-    BVH_CHECK(hipStreamSynchronize(stream));
-    outView->base = (const f4v*)blob;
-    outView->instOff16 = 0; outView->nodeOff16 = (uint32_t)(instBytes / 16); outView->triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
-    outView->instCount = n; outView->nodeCount = nodeCount; outView->triCount = triCount; outView->bytes = (uint32_t)total;
-    *outDev = blob; blob = nullptr;
-fail:
-    if (blob) hipFree(blob);
-    if (dBases) hipFree(dBases);
-    return err;
+}
+
+hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, hipStream_t stream)
+{
+    if (n) k_instance_records<<<cdiv(n, 256), 256, 0, stream>>>(src, table, n, rec, bounds);
+    return hipGetLastError();
+}
+
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+                                const BlobCopy* jobs, uint32_t njobs, hipStream_t stream)
+{
+    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, bounds, table, n, outInst);
+    if (njobs) k_blob_copy<<<dim3(64, njobs < 1024 ? njobs : 1024), 256, 0, stream>>>(jobs, njobs);
+    return hipGetLastError();
 }
 
 } // namespace pt

@@ -11,20 +11,50 @@
 
 namespace pt {
 
+struct WideHeader { uint32_t nodeCount, itemCount, depth, error; };      // written by the collapse kernel
+
+// Device buffers of one tree build. A bottom level built with PT_BUILD_FLAG_ALLOW_UPDATE and the top level keep them, so that a
+// refit / rebuild allocates nothing; a static bottom level frees them after the build.
+struct TreeBuffers {
+    float4* boxLo = nullptr; float4* boxHi = nullptr; uint32_t* bounds = nullptr;
+    uint64_t* keys = nullptr; uint64_t* keysSorted = nullptr; uint32_t* index = nullptr; uint32_t* indexSorted = nullptr;
+    void* sortTemp = nullptr; size_t sortTempBytes = 0;
+    uint64_t* leafKeys = nullptr; float4* leafLo = nullptr; float4* leafHi = nullptr;
+    int2* children = nullptr; int* parentInternal = nullptr; int* parentLeaf = nullptr;
+    float4* nodeLo = nullptr; float4* nodeHi = nullptr; uint32_t* arrival = nullptr;
+    int* binaryRootOf = nullptr; int* slotRefs = nullptr; uint32_t* leafDst = nullptr; uint32_t* slotOfPrim = nullptr;
+    WideHeader* header = nullptr;
+    uint32_t itemCapacity = 0, leafCapacity = 0;
+    void release();
+};
+
+// wide nodes a tree of nleaves leaves can need: 8-child nodes absorb 7 binary nodes each, the others hold leaves only
+inline uint32_t wide_node_capacity(uint32_t nleaves) { return nleaves * 3u / 5u + 2u; }
+
 struct Blas {
-    BvhNode* nodes = nullptr;
-    TriPacket* tris = nullptr;
+    WideNode* nodes = nullptr;
+    TriPacket* tris = nullptr;               // node order: the triangles of a node's leaf slots are contiguous
     float* rootBounds = nullptr;             // device: lo.xyz hi.xyz
-    uint32_t triCount = 0, leafCount = 0, nodeCount = 0;
+    uint32_t triCount = 0, leafCount = 0, nodeCount = 0, depth = 0, geometryCount = 0;
+    bool buildError = false, updatable = false;
+    TreeBuffers tree;                        // kept only when updatable
 };
 
 struct Tlas {
-    BvhNode* nodes = nullptr;
+    WideNode* nodes = nullptr;               // capacity wide_node_capacity(capacity)
+    uint32_t* order = nullptr;               // instance order list: the TLAS's "triangles"
+    float* rootBounds = nullptr;
     InstanceRecord* instances = nullptr;     // device, indexed by InstanceIndex
-    uint32_t instanceCount = 0, nodeCount = 0;
+    const float** blasBounds = nullptr;      // device, per instance: root bounds of its BLAS
+    uint32_t instanceCount = 0, capacity = 0;
     uint64_t triangleCount = 0;              // sum over instances
+    TreeBuffers tree;
 };
 
+// host -> device inputs of a top-level build, one upload per build
+struct InstanceSource { float transform[12]; uint32_t instanceID, mask, blasSlot, _pad; };
+struct BlasEntry { const WideNode* nodes; const TriPacket* tris; const float* rootBounds; uint32_t triCount, nodeCount, nodeBase, triBase; };
+struct BlobCopy { const void* src; void* dst; uint64_t n16; };
 
 // everything a render kernel needs about the scene, passed by value as a kernel argument
 struct SceneView {
@@ -56,7 +86,7 @@ struct FrameConstants { PtCamera cam; PtSceneData sd; PtGraphicsSettings gs; };
 
 struct DeviceCounters {
     unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
-    unsigned int mismatchCount, _pad;        // PT_DEBUG_BRUTE_FORCE: rays whose LBVH result differs from brute force
+    unsigned int mismatchCount, stackOverflows;   // PT_DEBUG_BRUTE_FORCE: rays whose BVH result differs from brute force | refused stack pushes (must be 0)
     float mismatchRay[16];                   // first such ray: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t -
 };
 
@@ -72,6 +102,14 @@ struct Context {
 
     std::map<uint64_t, Blas> blas; uint64_t nextBlasId = 1;
     Tlas tlas; bool haveTlas = false;
+    std::vector<uint64_t> tlasBlasIds;                // bottom levels the live TLAS refers to (pt_release_bottom_level checks)
+    std::vector<uint8_t> tlasUploadHost; void* tlasUploadDev = nullptr; size_t tlasUploadCap = 0;   // InstanceSource | BlasEntry | BlobCopy
+    WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check
+    uint32_t maxBlasDepth = 0, tlasInstanceCap = 0;
+    size_t blobCapacity = 0;
+    uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
+    bool validated = false; uint32_t* validateDev = nullptr;   // descriptor / index validation of the scene inputs (pt_api.hip make_views)
+    const void* validatedObjects = nullptr; uint32_t validatedObjectCount = 0;
 
     PtCamera camera{}; PtSceneData sceneData{}; PtGraphicsSettings settings{};
     bool haveCamera = false, haveSceneData = false, haveSettings = false;
@@ -96,11 +134,14 @@ struct Context {
 };
 
 // pt_bvh.hip
-hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& out);
+hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool allowUpdate, hipStream_t stream, Blas& out);
+hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& b);
+hipError_t build_tlas_prepare(Tlas& out, uint32_t n);
 hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out);
-struct BlobPiece { const BvhNode* nodes; const TriPacket* tris; uint32_t nodeCount, triCount, nodeBase, triBase; };
-hipError_t build_blob_device(const Tlas& tlas, const float* const* dBlasBounds, const std::vector<BlobPiece>& pieces,
-                             const std::vector<uint32_t>& pieceOfInstance, hipStream_t stream, void** outDev, BlobView* outView);
+hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, hipStream_t stream);
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+                                const BlobCopy* jobs, uint32_t njobs, hipStream_t stream);
+__host__ __device__ void invert_3x4(const float m[12], float out[12]);
 
 // pt_skin.hip
 hipError_t launch_skin(hipStream_t stream, const void* skeletal, const float* transforms, void* vertices, void* motion, uint32_t count);
@@ -110,6 +151,8 @@ hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, 
 hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx);
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
 hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
+hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap);
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 

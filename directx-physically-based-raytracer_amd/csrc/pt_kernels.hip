@@ -18,7 +18,7 @@ namespace pt {
 // ---------------------------------------------------------------------------------------------
 // shared device helpers
 // ---------------------------------------------------------------------------------------------
-constexpr int kLdsStackDepth = 24;      // traversal stack entries per lane kept in LDS (24 KB per 256-thread block)
+constexpr int kLdsStackDepth = 12;      // node-group stack entries (8 B) per lane kept in LDS (24 KB per 256-thread block)
 
 struct RayDesc { v3 o, d; float tmin, tmax; };
 
@@ -214,15 +214,16 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
     float LinearDepth = INFINITY, NormalizedDepth = cam.IsNormalizedDepthReversed ? 0.0f : 1.0f;
     float u, v;
     const RayDesc ray = generate_pinhole_ray(cam, valid ? x : 0u, y, fv.width, fv.height, u, v);
-    TraceStats st; st.nodes = 0; st.tris = 0;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     Hit hit;
     HitGeometry hg;
     if constexpr (MODE == 0) {
-        __shared__ int ldsStack[kLdsStackDepth * 256];
-        int spill[kStackSize - kLdsStackDepth];
-        TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
-        hit = trace_closest<STATS>(sv.accel, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st);
-        if (hit.inst != ~0u) hg = load_hit_geometry(sv, hit.inst, hit.slot);
+        __shared__ uint2 ldsStack[kLdsStackDepth * 256];
+        uint2 spill[kStackSize - kLdsStackDepth];
+        GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+        BlobReader<false> blob; blob.p = bv.base;
+        hit = trace_single<STATS, false, false>(blob, bv, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st, nullptr);
+        if (hit.inst != ~0u) hg = load_hit_geometry<false>(blob, bv, hit.inst, hit.slot);
     } else {
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
         constexpr bool LDS = MODE == 1;
@@ -236,14 +237,15 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
         } else {
             blob.p = bv.base;
         }
-        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 8u + (threadIdx.x >> 6) * kFlatWaveLds;
         // pixels outside the frame carry an empty ray interval: they hit nothing but their lanes still serve work items
         hit = trace_closest_flat<STATS, LDS>(blob, bv, alpha_context(sv), ray.o, ray.d, valid ? ray.tmin : 1.0f, valid ? ray.tmax : 0.0f,
-                                             (int*)smem, ldsWave, &st);
+                                             (uint2*)smem, ldsWave, &st);
         if (!valid) return;
         if (hit.inst != ~0u) hg = load_hit_geometry<LDS>(blob, bv, hit.inst, hit.slot);
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+    if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&counters->primaryRays, (unsigned long long)fv.width * fv.localRows);
 
     if (hit.inst != ~0u) {
@@ -622,20 +624,21 @@ __global__ __launch_bounds__(256) void k_shade(SceneView sv, FrameView fv, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
-    __shared__ int ldsStack[kLdsStackDepth * 256];
-    int spill[kStackSize - kLdsStackDepth];
-    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
-    TraceStats st; st.nodes = 0; st.tris = 0;
+    __shared__ uint2 ldsStack[kLdsStackDepth * 256];
+    uint2 spill[kStackSize - kLdsStackDepth];
+    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    BlobReader<false> blob; blob.p = bv.base;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
         const Hit h = trace_brute_force(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w);
-        const Hit b = trace_closest<false>(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        const Hit b = trace_single<false, false, false>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st, nullptr);
         if (b.inst != h.inst || (h.inst != ~0u && (b.slot != h.slot || b.u != h.u || b.v != h.v))) {
             if (atomicAdd(&counters->mismatchCount, 1u) == 0u) {
                 float* m = counters->mismatchRay;
@@ -646,13 +649,15 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, AlphaContext
         }
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
     }
+    if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
 }
 
 // Traversal kernel (phase-aligned schedule, pt_trace2.hpp). Dynamic LDS: traversal stack (kStackLds entries
 // per lane) | candidate lists (kCandidates per lane) | the scene blob when it fits (LDS = true).
-constexpr int kStackLds2 = 10;                 // TLAS + BLAS share this stack in the phased schedule; deeper entries spill
+constexpr int kStackLds2 = 8;                  // TLAS + BLAS node groups (8 B) share this stack in the phased schedule; deeper entries spill
 // phased schedule: stack | candidate lists | per-wave work-item exchange
-constexpr uint32_t kExtendLdsFixed = (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + 4u * kPhasedWaveLds;
+constexpr uint32_t kStackLds2Bytes = (uint32_t)kStackLds2 * 256u * 8u;
+constexpr uint32_t kExtendLdsFixed = kStackLds2Bytes + (uint32_t)kCandidates * 256u * 4u + 4u * kPhasedWaveLds;
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
 template <bool STATS, bool LDS, bool WRITE_T = false, bool FLAT = false>
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     if (bq * 256u >= n) return;                                   // block-uniform: nothing to do, skip the staging
-    int* ldsStack = (int*)smem;
+    uint2* ldsStack = (uint2*)smem;
     BlobReader<LDS> blob;
     if constexpr (LDS) {
         f4v* dst = (f4v*)(smem + kFixed);
@@ -675,10 +680,10 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
     } else {
         blob.p = bv.base;
     }
-    TraceStats st; st.nodes = 0; st.tris = 0;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     if constexpr (FLAT) {
         // whole waves enter the traversal (lanes past the end carry a ray that can hit nothing): its lanes trade work items
-        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+        unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 8u + (threadIdx.x >> 6) * kFlatWaveLds;
         for (uint32_t base = bq * 256u; base < n; base += nbq * 256u) {
             const uint32_t local = base + threadIdx.x;
             const bool valid = local < n;
@@ -692,8 +697,8 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
             }
         }
     } else {
-        uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
-        unsigned char* ldsWave = smem + (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
+        uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2Bytes);
+        unsigned char* ldsWave = smem + kStackLds2Bytes + (uint32_t)kCandidates * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
         for (uint32_t base = bq * 256u; base < n; base += nbq * 256u) {     // whole waves again: phase B trades work items
             const uint32_t local = base + threadIdx.x;
             const bool valid = local < n;
@@ -708,6 +713,7 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
         }
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+    if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
 }
 
 // One whole round in ONE launch: a block traces the rays of its tile and shades the same entries right away -- the hit stays in
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
 
     if (bq * 256u < nT) {                                        // block-uniform
-        int* ldsStack = (int*)smem;
+        uint2* ldsStack = (uint2*)smem;
         BlobReader<LDS> blob;
         if constexpr (LDS) {
             f4v* dst = (f4v*)(smem + kFixed);
@@ -744,7 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             blob.p = bv.base;
         }
         AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
-        TraceStats st; st.nodes = 0; st.tris = 0;
+        TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
         for (uint32_t base = bq * 256u; base < nT; base += nbq * 256u) {
             const uint32_t local = base + threadIdx.x;
             const bool valid = local < nT;
@@ -755,11 +761,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (!valid) { o.w = 1.0f; d.w = 0.0f; }               // empty interval: hits nothing, but the lane still serves work items
             Hit h;
             if constexpr (FLAT) {
-                unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 4u + (threadIdx.x >> 6) * kFlatWaveLds;
+                unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 8u + (threadIdx.x >> 6) * kFlatWaveLds;
                 h = trace_closest_flat<false, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st);
             } else {
-                uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2 * 256 * 4);
-                unsigned char* ldsWave = smem + (uint32_t)(kStackLds2 + kCandidates) * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
+                uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2Bytes);
+                unsigned char* ldsWave = smem + kStackLds2Bytes + (uint32_t)kCandidates * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
                 h = trace_closest_v2<false, LDS, kStackLds2>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsCand, ldsWave, &st);
             }
             bool toTraced = false, toFresh = false;
@@ -770,6 +776,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
         }
+        if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
     }
     for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
         const uint32_t local = tile * 256u + threadIdx.x;
@@ -784,38 +791,95 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_extend(AccelView av, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
-    __shared__ int ldsStack[kLdsStackDepth * 256];
-    int spill[kStackSize - kLdsStackDepth];
-    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
-    TraceStats st; st.nodes = 0; st.tris = 0;
+    __shared__ uint2 ldsStack[kLdsStackDepth * 256];
+    uint2 spill[kStackSize - kLdsStackDepth];
+    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    BlobReader<false> blob; blob.p = bv.base;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
         const uint32_t i = sq * segCap + local;
         const float4 o = q.r0[i], d = q.r1[i];
-        const Hit h = trace_closest<STATS>(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st);
+        const Hit h = trace_single<STATS, false, false>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st, nullptr);
         q.hit[i] = make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+    if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
 }
 
 static uint32_t persistent_grid(int device);
 
 // batch entry points for direct-lighting style consumers (RTXDI bridge shape), see include/ptamd.h
-__global__ __launch_bounds__(256) void k_visibility(AccelView av, AlphaContext ac, const float4* __restrict__ rays, uint32_t count, float4* __restrict__ out)
+__global__ __launch_bounds__(256) void k_visibility(BlobView bv, AlphaContext ac, const float4* __restrict__ rays, uint32_t count, float4* __restrict__ out,
+                                                    DeviceCounters* counters)
 {
-    __shared__ int ldsStack[kLdsStackDepth * 256];
-    int spill[kStackSize - kLdsStackDepth];
-    TraversalStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    __shared__ uint2 ldsStack[kLdsStackDepth * 256];
+    uint2 spill[kStackSize - kLdsStackDepth];
+    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    BlobReader<false> blob; blob.p = bv.base;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const float4 o = rays[2 * (size_t)i], d = rays[2 * (size_t)i + 1];
         v3 vis;
-        const bool unoccluded = trace_visibility(av, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, vis);
-        out[i] = make_float4(vis.x, vis.y, vis.z, unoccluded ? 1.0f : 0.0f);
+        const Hit h = trace_single<false, false, true>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, stack, &st, &vis);
+        out[i] = make_float4(vis.x, vis.y, vis.z, h.inst == ~0u ? 1.0f : 0.0f);
     }
+    if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
+}
+
+// developer aid (pt_debug_trace_ray): one ray through trace_single with a step log
+__global__ __launch_bounds__(256) void k_debug_trace(BlobView bv, AlphaContext ac, float4 o, float4 d, uint32_t* log, uint32_t logCap)
+{
+    __shared__ uint2 ldsStack[kLdsStackDepth * 256];
+    uint2 spill[kStackSize - kLdsStackDepth];
+    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    BlobReader<false> blob; blob.p = bv.base;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
+    // lane 0 traces the ray and logs; the other lanes trace neighbours of it (rotated a little more per lane) without a log, so that
+    // the logged walk runs under the divergence of a real launch
+    const float a = 0.02f * (float)threadIdx.x, ca = cosf(a), sa = sinf(a);
+    const v3 dd = V3(d.x * ca - d.z * sa, d.y, d.x * sa + d.z * ca);
+    trace_single<false, false, false, GroupStack<kLdsStackDepth>, true>(blob, bv, ac, V3(o.x, o.y, o.z), dd, o.w, d.w, stack, &st, nullptr, log, threadIdx.x == 0 ? logCap : 0u);
+}
+
+hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap)
+{
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    k_debug_trace<<<1, 256, 0, c.stream>>>(c.blob, ac, make_float4(ray8[0], ray8[1], ray8[2], ray8[3]), make_float4(ray8[4], ray8[5], ray8[6], ray8[7]), devLog, logCap);
+    return hipGetLastError();
+}
+
+// scene-input validation (pt_api.hip validate_scene): every descriptor index ObjectData carries must name a heap entry of the
+// right kind. out: error member (1 Vertices, 2 Indices, 3 MotionVectors, 4 TextureMapInfo) | object | descriptor | 1 = wrong kind
+__global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uint32_t count, const HeapEntry* __restrict__ heap, uint32_t heapCount, uint32_t* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const PtObjectData* od = &objects[i];
+    uint32_t err = 0, desc = 0, kind = 0;
+    const uint32_t md[3] = { od->MeshDescriptors.Vertices, od->MeshDescriptors.Indices, od->MeshDescriptors.MotionVectors };
+    for (uint32_t k = 0; k < 3 && !err; k++) {
+        if (md[k] == ~0u) continue;                       // absent (a mesh that is never hit needs none; a hit dereferences Vertices / Indices only when normals exist)
+        if (md[k] >= heapCount) { err = k + 1; desc = md[k]; }
+        else if (heap[md[k]].kind != kKindBuffer) { err = k + 1; desc = md[k]; kind = 1; }
+    }
+    for (uint32_t k = 0; k < 7 && !err; k++) {
+        const uint32_t d = od->TextureMapInfoArray[k].Descriptor;
+        if (d == ~0u) continue;
+        if (d >= heapCount) { err = 4; desc = d; }
+        else if (heap[d].kind != kKindTexture2D) { err = 4; desc = d; kind = 1; }
+    }
+    if (err && atomicCAS(&out[0], 0u, err) == 0u) { out[1] = i; out[2] = desc; out[3] = kind; }
+}
+
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out)
+{
+    if (count) k_validate_objects<<<(count + 255) / 256, 256, 0, stream>>>(objects, count, heap, heapCount, out);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_bsdf_evaluate(const float* __restrict__ q, uint32_t count, float* __restrict__ r)
@@ -839,7 +903,7 @@ hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, 
 {
     if (!count) return hipSuccess;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
-    k_visibility<<<persistent_grid(c.device), 256, 0, c.stream>>>(sv.accel, ac, (const float4*)rays, count, (float4*)out);
+    k_visibility<<<persistent_grid(c.device), 256, 0, c.stream>>>(c.blob, ac, (const float4*)rays, count, (float4*)out, c.counters);
     return hipGetLastError();
 }
 
@@ -965,10 +1029,10 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
         const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
-        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
+        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, c.blob, ac, qout, segCap, cout, c.counters);
         else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
-            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
-            else k_extend<false><<<grid, 256, 0, c.stream>>>(sv.accel, ac, qout, segCap, cout, c.counters);
+            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            else k_extend<false><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
         } else {
             const bool wt = aux != nullptr;                            // denoiser modes need CommittedRayT
             #define PT_EXT2(S, L, W, F) k_extend2<S, L, W, F><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters)

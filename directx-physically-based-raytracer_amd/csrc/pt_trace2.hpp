@@ -1,26 +1,24 @@
-// pt_trace2.hpp -- two-level traversal over the compact scene blob (gfx950): the phase-aligned schedule below and, further
-// down, the flat schedule with wave-compacted work items for scenes of at most kFlatInstances instances.
+// pt_trace2.hpp -- traversal of the compact scene blob (gfx950): the BLAS work-item routine over compressed wide nodes, the
+// phase-aligned two-level schedule, the flat schedule with wave-compacted work items for scenes of at most kFlatInstances
+// instances, and the plain one-lane-one-ray two-level walk (G-buffer rays, shadow rays, validation).
 //
-// Same closest-hit semantics and arithmetic as pt_trace.hpp (tri_test / commit are shared), different
-// schedules, designed for wave64 SIMD efficiency. Phase-aligned:
+// Same closest-hit semantics and arithmetic everywhere (tri_test / commit are shared), different schedules, designed for
+// wave64 SIMD efficiency. Phase-aligned:
 //   phase A  every lane walks the TLAS only and collects up to K candidate instances in LDS
-//   phase B  candidate k of every lane is processed in lock-step: world-box re-test against the current
-//            best t, ray transform + Woop setup (the expensive block runs once per round, not once per
-//            straggling lane), then a BLAS-only while-while traversal
-// and back to phase A while the TLAS walk is unfinished. With interleaved TLAS/BLAS states (pt_trace.hpp) a
-// wave executed the union of {TLAS node, instance entry, BLAS node, leaf, restore} every outer iteration.
+//   phase B  the candidates of the whole wave become work items (ray, instance) that any free lane processes: late cull
+//            against the current best t, ray transform + Woop setup, BLAS-only traversal
+// and back to phase A while the TLAS walk is unfinished.
 //
 // The blob is ONE contiguous allocation addressed in 16-byte units so that the identical code reads it from
 // HBM/L2 (large scenes) or from LDS (scenes that fit: the block stages the blob once, "LDS-staged node /
-// triangle packets"):   [ InstanceT x instCount | BvhNode x nodeCount | TriPacket x triCount ]
-// TLAS nodes come first in the node array (root = 0); a BLAS's nodes / packets are contiguous at
-// nodeBase / triBase. Node child references stay relative to their own tree.
+// triangle packets"):   [ InstanceT x instCount | WideNode x nodeCount | TriPacket x triCount | instance order u32 x instCount ]
+// TLAS nodes come first in the node array (root = 0); a BLAS's nodes / packets are contiguous at nodeBase / triBase. Child
+// and triangle references of a node stay relative to their own tree. The TLAS's "triangles" index the instance order list.
 #pragma once
 #include "pt_trace.hpp"
 
 namespace pt {
 
-typedef float f4v __attribute__((ext_vector_type(4)));
 #define PT_LDS_AS __attribute__((address_space(3)))
 
 struct alignas(16) InstanceT {        // 144 B = 9 x 16
@@ -34,13 +32,13 @@ static_assert(sizeof(InstanceT) == 144, "layout");
 
 struct BlobView {
     const f4v* base;                   // device pointer to the blob
-    uint32_t instOff16, nodeOff16, triOff16;   // section starts in 16-byte units
+    uint32_t instOff16, nodeOff16, triOff16, orderOff16;   // section starts in 16-byte units
     uint32_t instCount, nodeCount, triCount;
     uint32_t bytes;                    // whole blob
 };
 
 constexpr uint32_t kInst16 = 9;        // 16-byte units per instance record
-constexpr uint32_t kNode16 = 4;
+constexpr uint32_t kNode16 = 5;
 constexpr uint32_t kTri16 = 3;
 constexpr int kCandidates = 8;         // K: candidate instances gathered per phase A
 
@@ -48,19 +46,31 @@ template <bool LDS> struct BlobReader;
 template <> struct BlobReader<false> {
     const f4v* p;
     PT_DEV f4v ld(uint32_t i) const { return p[i]; }
+    PT_DEV uint32_t ld32(uint32_t i) const { return ((const uint32_t*)p)[i]; }
 };
 template <> struct BlobReader<true> {
     const PT_LDS_AS f4v* p;
     PT_DEV f4v ld(uint32_t i) const { return p[i]; }
+    PT_DEV uint32_t ld32(uint32_t i) const { return ((const PT_LDS_AS uint32_t*)p)[i]; }
 };
 
-PT_DEV void node_test_v(f4v c0xy, f4v c1xy, f4v cz, v3 idir, v3 ood, float tmin, float tmax, bool& hit0, bool& hit1, float& tn0, float& tn1)
+// One node visit: pops the highest-priority hit child off G, fetches that node and tests its eight boxes. On return G is the
+// group of the fetched node's hit internal children, T the group of its hit triangles; the rest of the old G went on the stack.
+template <bool STATS, bool LDS, typename STACK>
+PT_DEV void visit_node(const BlobReader<LDS>& blob, uint32_t nodeBase16, const BoxRay& br, float tmin, float tmax, uint2& G, uint2& T,
+                       STACK& stack, TraceStats* stats)
 {
-    BvhNode n;
-    n.c0xy = make_float4(c0xy.x, c0xy.y, c0xy.z, c0xy.w);
-    n.c1xy = make_float4(c1xy.x, c1xy.y, c1xy.z, c1xy.w);
-    n.cz = make_float4(cz.x, cz.y, cz.z, cz.w);
-    node_test(n, idir, ood, tmin, tmax, hit0, hit1, tn0, tn1);
+    const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
+    G.y &= ~(1u << bit);
+    if (G.y > 0x00FFFFFFu) stack.push(G);
+    const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
+    const uint32_t rel = (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot));
+    const uint32_t a = nodeBase16 + (G.x + rel) * kNode16;
+    const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3), n4 = blob.ld(a + 4);
+    if (STATS) stats->nodes++;
+    const uint32_t hits = wide_node_hits(n0, n1, n2, n3, n4, br, tmin, tmax);
+    G = make_uint2(__float_as_uint(n1.x), (hits & 0xFF000000u) | (__float_as_uint(n0.w) >> 24));
+    T = make_uint2(__float_as_uint(n1.y), hits & 0x00FFFFFFu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -98,40 +108,29 @@ PT_DEV f4v trace_item(const BlobReader<LDS>& blob, const BlobView& bv, const Alp
                          w1.x * id.x + w1.y * id.y + w1.z * id.z,
                          w2.x * id.x + w2.y * id.y + w2.z * id.z);
         const RaySetup rs = ray_setup(rd);
-        const v3 bidir = safe_inv(rd), bood = ro * bidir;
-        const uint32_t triBase = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-        const uint32_t nodeBase = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-        stack.push(kEntryRestore);
-        int c = blas_root_entry(__float_as_uint(blob.ld(ia + 5).y));      // single-leaf BLAS: straight to the leaf
+        const BoxRay br = box_ray(ro, rd);
+        const uint32_t triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+        const uint32_t nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
+        const uint32_t ntri = __float_as_uint(blob.ld(ia + 5).y);
+        const bool single = blas_single_leaf(ntri);                          // single-leaf BLAS: straight to its triangles
+        uint2 G = root_node_group(single), T = root_tri_group(single, ntri);
+        const int floor = stack.sp;                                          // the caller's entries below stay untouched
         while (true) {
-            while (c >= 0 && c < kEntryRestore) {
-                const uint32_t a = nodeBase + (uint32_t)c * kNode16;
-                const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
-                if (STATS) stats->nodes++;
-                bool h0, h1; float t0, t1;
-                node_test_v(n0, n1, n2, bidir, bood, itmin, hi.t, h0, h1, t0, t1);
-                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    int nearc = c0, farc = c1;
-                    if (t1 < t0) { nearc = c1; farc = c0; }
-                    stack.push(farc);
-                    c = nearc;
-                } else if (h0) c = c0;
-                else if (h1) c = c1;
-                else c = stack.pop();
-            }
-            if (c == kEntryRestore) break;
-            const uint32_t leaf = (uint32_t)~c;
-            const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-            for (uint32_t i = 0; i < count; i++) {
-                const uint32_t ta = triBase + (first + i) * kTri16;
+            if (G.y > 0x00FFFFFFu) visit_node<STATS, LDS>(blob, nodeBase16, br, itmin, hi.t, G, T, stack, stats);
+            while (T.y) {
+                const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
+                T.y &= T.y - 1u;
+                const uint32_t ta = triBase16 + i * kTri16;
                 const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
                 if (STATS) stats->tris++;
                 float t, u, v;
                 if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                    commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), first + i);
+                    commit_candidate(ac, __float_as_uint(pc.w), hi, itmin, t, u, v, x, __float_as_uint(pa.w), __float_as_uint(pb.w), i);
             }
-            c = stack.pop();
+            if (G.y <= 0x00FFFFFFu) {
+                if (stack.sp == floor) break;
+                G = stack.pop();
+            }
         }
     }
     return (f4v){ hi.t, hi.u, hi.v, __uint_as_float(hi.slot) };
@@ -156,13 +155,12 @@ constexpr uint32_t kPhasedWaveLds = 64u * 32u + kPhasedItems * 16u + kPhasedItem
 
 template <bool STATS, bool LDS, int STACK_DEPTH>
 PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                            int* ldsStack, uint32_t* ldsCand, unsigned char* ldsWave, TraceStats* stats)
+                            uint2* ldsStack, uint32_t* ldsCand, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     if (bv.instCount == 0) return h;
-    int spill[kStackSize - STACK_DEPTH];
-    TraversalStack<STACK_DEPTH> stack; stack.init(ldsStack, spill);
-    stack.push(kEntryDone);
+    uint2 spill[kStackSize - STACK_DEPTH];
+    GroupStack<STACK_DEPTH> stack; stack.init(ldsStack, spill);
     uint32_t* cand = ldsCand + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -171,35 +169,26 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
     uint32_t* items = (uint32_t*)(ldsWave + 64u * 32u + kPhasedItems * 16u);  // [item]: lane | instance << 8
     rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
 
-    const v3 idir = safe_inv(d), ood = o * idir;
-    int cur = tlas_root_entry(bv.instCount);
+    const BoxRay br = box_ray(o, d);
+    const bool oneInstance = bv.instCount == 1u;                            // a TLAS of one leaf: straight to the instance
+    uint2 G = root_node_group(oneInstance), T = root_tri_group(oneInstance, 1u);
     bool tlasDone = !(tmin <= tmax);                                        // an empty interval (a lane without a ray) has nothing to walk
     while (true) {
-        // ---------------- phase A: TLAS walk, collect candidates
+        // ---------------- phase A: TLAS walk, collect candidates (the TLAS's "triangles" are entries of the instance order list)
         uint32_t nCand = 0;
         while (!tlasDone && nCand < (uint32_t)kCandidates) {
-            if (cur >= 0 && cur < kEntryRestore) {
-                const uint32_t a = bv.nodeOff16 + (uint32_t)cur * kNode16;
-                const f4v n0 = blob.ld(a), n1 = blob.ld(a + 1), n2 = blob.ld(a + 2), n3 = blob.ld(a + 3);
-                if (STATS) stats->nodes++;
-                bool h0, h1; float t0, t1;
-                node_test_v(n0, n1, n2, idir, ood, tmin, h.t, h0, h1, t0, t1);
-                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    int nearc = c0, farc = c1;
-                    if (t1 < t0) { nearc = c1; farc = c0; }
-                    stack.push(farc);
-                    cur = nearc;
-                } else if (h0) cur = c0;
-                else if (h1) cur = c1;
-                else cur = stack.pop();
-            } else if (cur == kEntryDone) {
-                tlasDone = true;
-            } else {
-                const uint32_t x = (uint32_t)~cur;
+            if (T.y) {
+                const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
+                T.y &= T.y - 1u;
+                const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
                 const f4v mk = blob.ld(bv.instOff16 + x * kInst16 + 5);      // mask, triCount, InstanceID, -
                 if ((__float_as_uint(mk.x) & 0xFFu) && __float_as_uint(mk.y) != 0u) { cand[nCand * 256] = x; nCand++; }
-                cur = stack.pop();
+            } else if (G.y > 0x00FFFFFFu) {
+                visit_node<STATS, LDS>(blob, bv.nodeOff16, br, tmin, h.t, G, T, stack, stats);
+            } else if (stack.sp > 0) {
+                G = stack.pop();
+            } else {
+                tlasDone = true;
             }
         }
         // ---------------- phase B: the wave's candidates as compacted work items, batch by batch
@@ -230,6 +219,7 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
         }
         if (!__ballot(!tlasDone)) break;                                    // the wave leaves together: finished lanes keep serving items
     }
+    stats->overflow += stack.overflow;
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;
 }
@@ -249,15 +239,15 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
 // full lanes (measured before compaction: 1.9 mesh rounds per wave at 38 % occupancy + 2.4 quad rounds at 54 %; now
 // ~128 items in 2 rounds). Same tri_test / is_better arithmetic, so the result is bit-identical to the other schedules.
 constexpr uint32_t kFlatInstances = 32;
-constexpr int kStackLdsFlat = 8;                                             // BLAS-only stacks are shallow; deeper entries spill
+constexpr int kStackLdsFlat = 4;                                             // BLAS-only group stacks are shallow (one entry per level); deeper entries spill
 constexpr uint32_t kFlatItems = 192;                                         // items per batch and wave
 // LDS per wave for the exchange: rays 64 x 32 B | results kFlatItems x 16 B | items kFlatItems x 4 B
 constexpr uint32_t kFlatWaveLds = 64u * 32u + kFlatItems * 16u + kFlatItems * 4u;
-constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 4u + 4u * kFlatWaveLds;
+constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 8u + 4u * kFlatWaveLds;
 
 template <bool STATS, bool LDS>
 PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                              int* ldsStack, unsigned char* ldsWave, TraceStats* stats)
+                              uint2* ldsStack, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     uint32_t quads = 0, meshes = 0;
@@ -276,7 +266,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
             const uint32_t bit = (tn <= tf * 1.0000004f) ? (1u << x) : 0u;
             if (blas_single_leaf(ntri)) quads |= bit; else meshes |= bit;   // uniform select
         }
-        if (STATS) stats->nodes += (bv.instCount + 1u) / 2u;                // two boxes = one node's worth of bytes
+        if (STATS) stats->nodes += (bv.instCount * 2u + 4u) / 5u;           // an instance box is 32 B, a node 80 B: counted by bytes
     }
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -287,8 +277,8 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
     const uint32_t nm = (uint32_t)__builtin_popcount(meshes), nq = (uint32_t)__builtin_popcount(quads);
     if (!__ballot((nm | nq) != 0u)) return h;
     rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
-    int spill[kStackSize - kStackLdsFlat];
-    TraversalStack<kStackLdsFlat> stack; stack.init(ldsStack, spill);
+    uint2 spill[kStackSize - kStackLdsFlat];
+    GroupStack<kStackLdsFlat> stack; stack.init(ldsStack, spill);
 
     uint32_t km = 0, kq = 0;                                                // levels (k-th set bit of every lane) already done; uniform
     bool firstBatch = true;
@@ -353,7 +343,104 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
         __builtin_amdgcn_wave_barrier();
         km = km2; kq = kq2; firstBatch = false;
     }
+    stats->overflow += stack.overflow;
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One lane, one ray, one stack over both levels: the plain form of TraceRay. ANYHIT = false: closest hit (primary rays of the
+// G-buffer pass in scenes too large for the flat schedule, PT_DEBUG_TRAVERSAL_V1 cross-checks). ANYHIT = true:
+// TraceRay<RAY_FLAG_FORCE_NON_OPAQUE | RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH> with the coloured-visibility IsOpaque
+// (RaytracingHelpers.hlsli:7-55; the shape RTXDIAppBridge.hlsli:418-439 uses for shadow rays): every triangle inside
+// (tmin, tmax) is a candidate exactly once (no leaf is visited twice), a blocking one ends the search; vis = product of the
+// candidates' transmittances, the returned hit has inst == ~0u when nothing was committed.
+// An instance transition parks the TLAS state as three stack entries: G, T (instances still to enter) and a marker.
+// LOG (developer aid, pt_debug_trace_ray): every step of the walk is appended to log[] as (code, a, b, sp) words.
+template <bool STATS, bool LDS, bool ANYHIT, typename STACK, bool LOG = false>
+PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
+                        STACK& stack, TraceStats* stats, v3* vis, uint32_t* log = nullptr, uint32_t logCap = 0)
+{
+    uint32_t nlog = 0;
+    #define PT_LOG(code, a, b) do { if (LOG && 4u * nlog + 4u <= logCap) { log[4 * nlog] = (code); log[4 * nlog + 1] = (a); log[4 * nlog + 2] = (b); log[4 * nlog + 3] = (uint32_t)stack.sp; nlog++; } } while (0)
+    Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
+    if (ANYHIT) *vis = V3(1.0f, 1.0f, 1.0f);
+    if (bv.instCount == 0 || !(tmin <= tmax)) return h;
+    constexpr uint32_t kMarker = 0xFFFFFFFFu;
+    BoxRay br = box_ray(o, d);
+    RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    v3 ro = o;
+    // curInst == ~0u: the walk is in the top level. (An integer on purpose: with a separate `bool bottom` flag hipcc 7.2 -O3 kept the
+    // flag where a lane leaving its BLAS cleared it for its neighbours too -- seen on hardware with pt_debug_trace_ray.)
+    uint32_t nodeBase16 = bv.nodeOff16, triBase16 = 0, curInst = ~0u;
+    const bool oneInstance = bv.instCount == 1u;
+    uint2 G = root_node_group(oneInstance), T = root_tri_group(oneInstance, 1u);
+    stack.sp = 0;
+    while (true) {
+        if (T.y) {
+            const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
+            T.y &= T.y - 1u;
+            if (curInst == ~0u) {                                           // a TLAS "triangle": enter the instance
+                const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
+                const uint32_t ia = bv.instOff16 + x * kInst16;
+                const f4v mk = blob.ld(ia + 5);
+                const uint32_t ntri = __float_as_uint(mk.y);
+                if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
+                    const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
+                    ro = V3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w, w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
+                    const v3 rd = V3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z, w2.x * d.x + w2.y * d.y + w2.z * d.z);
+                    rs = ray_setup(rd);
+                    br = box_ray(ro, rd);
+                    nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
+                    triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+                    PT_LOG(1u, x, T.y);
+                    stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
+                    const bool single = blas_single_leaf(ntri);
+                    G = root_node_group(single); T = root_tri_group(single, ntri);
+                    curInst = x;
+                }
+            } else {
+                const uint32_t ta = triBase16 + i * kTri16;
+                const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+                if (STATS) stats->tris++;
+                PT_LOG(2u, curInst, i);
+                float t, u, v;
+                if (tri_test(rs, ro, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v)) {
+                    const uint32_t geom = __float_as_uint(pa.w), prim = __float_as_uint(pb.w);
+                    if (!ANYHIT) {
+                        commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, curInst, geom, prim, i);
+                    } else if (t > tmin && t < tmax) {
+                        const PtObjectData* od = &ac.objects[ac.instances[curInst].instanceID + geom];
+                        TexCoords tc;
+                        get_texture_coordinates(od, ac.heap, prim, u, v, tc);
+                        if (is_opaque_visibility(od, ac.heap, ac.srgbLut, tc, *vis)) {
+                            h.t = t; h.u = u; h.v = v; h.inst = curInst; h.geom = geom; h.prim = prim; h.slot = i;
+                            break;
+                        }
+                    }
+                }
+            }
+        } else if (G.y > 0x00FFFFFFu) {
+            PT_LOG(3u, G.x, G.y);
+            visit_node<STATS, LDS>(blob, nodeBase16, br, tmin, ANYHIT ? tmax : h.t, G, T, stack, stats);
+            PT_LOG(4u, G.y, T.y);
+        } else if (stack.sp > 0) {
+            G = stack.pop();
+            PT_LOG(5u, G.x, G.y);
+            if (G.x == kMarker && G.y == 0u) {                              // leave the BLAS: back to the world-space ray
+                if (stack.overflow) break;                                  // a refused push left the parked state incomplete (unreachable: the builders bound the depth)
+                T = stack.pop(); G = stack.pop();
+                PT_LOG(6u, G.y, T.y);
+                br = box_ray(o, d); nodeBase16 = bv.nodeOff16; curInst = ~0u;
+            }
+        } else {
+            break;
+        }
+    }
+    PT_LOG(7u, h.inst, h.slot);
+    #undef PT_LOG
+    stats->overflow += stack.overflow;
+    if (!ANYHIT && h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
     return h;
 }
 

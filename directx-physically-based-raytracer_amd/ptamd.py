@@ -24,7 +24,7 @@ EXPORTS = [
     "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
-    "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_enable_kernel_timing", "pt_get_kernel_timing", "pt_get_round_timing",
+    "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_debug_download_blob", "pt_debug_trace_ray", "pt_enable_kernel_timing", "pt_get_kernel_timing", "pt_get_round_timing",
 ]
 
 
@@ -61,13 +61,19 @@ class Sharding(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("PrimaryRays", C.c_uint64), ("SecondaryRays", C.c_uint64), ("NodesVisited", C.c_uint64),
                 ("TrianglesTested", C.c_uint64), ("WavefrontIterations", C.c_uint64), ("BvhMismatches", C.c_uint64),
-                ("_reserved", C.c_uint64 * 2)]
+                ("StackOverflows", C.c_uint64), ("_reserved", C.c_uint64 * 1)]
+
+
+class BlobLayout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("InstanceOffset16", "NodeOffset16", "TriangleOffset16", "OrderOffset16",
+                                          "InstanceCount", "NodeCount", "TriangleCount", "Bytes")]
 
 
 class AccelStats(C.Structure):
     _fields_ = [("InstanceCount", C.c_uint32), ("BottomLevelCount", C.c_uint32), ("TriangleCount", C.c_uint64),
                 ("NodeBytes", C.c_uint64), ("TriangleBytes", C.c_uint64), ("NodeSizeBytes", C.c_uint32),
-                ("TriangleSizeBytes", C.c_uint32)]
+                ("TriangleSizeBytes", C.c_uint32), ("MaxBottomLevelDepth", C.c_uint32), ("TopLevelDepth", C.c_uint32),
+                ("BlobBytes", C.c_uint64)]
 
 
 def load_library():
@@ -80,7 +86,7 @@ def load_library():
         # torch bundles its own libamdhip64.so.7; import it first so libptamd.so binds to the SAME HIP
         # runtime (two runtimes in one process cannot both open the device, and tensors would not be shared)
         import torch  # noqa: F401
-        lib = C.CDLL(os.environ.get("PTAMD_LIB_AB", LIB_PATH))      # PTAMD_LIB_AB: developer aid, A/B-compare two builds on one box
+        lib = C.CDLL(LIB_PATH)
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [C.c_void_p]
         lib.pt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -110,6 +116,8 @@ def load_library():
         lib.pt_reset_counters.argtypes = [C.c_void_p]
         lib.pt_set_debug_flags.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_debug_read_mismatch.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pt_debug_download_blob.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.pt_debug_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         lib.pt_enable_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.pt_get_round_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         lib.pt_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -185,6 +193,14 @@ class DeviceContext:
         return {"extend_ms": e.value, "shade_ms": s.value, "extend_launches": ne.value, "shade_launches": ns.value,
                 "round_ms": r.value, "round_launches": nr.value}
 
+    def download_blob(self):
+        """(layout, bytes) of the traversal copy of the scene -- for the structural checks in tests/."""
+        lay = BlobLayout()
+        self.check(self.lib.pt_debug_download_blob(self.handle, None, 0, C.byref(lay)))
+        buf = np.zeros(lay.Bytes, np.uint8)
+        self.check(self.lib.pt_debug_download_blob(self.handle, C.c_void_p(buf.ctypes.data), buf.nbytes, C.byref(lay)))
+        return lay, buf
+
     def accel_stats(self):
         s = AccelStats()
         self.check(self.lib.pt_get_accel_stats(self.handle, C.byref(s)))
@@ -242,6 +258,41 @@ class Scene:
         self._skin_cache = {}
         self.CreateAccelerationStructures()
 
+    def close(self):
+        """~Scene (Source/Scene.ixx:108-123): the bottom levels this scene built go back to the context. The live top level
+        dies with them: a render before the next scene's build answers PT_ERROR_NOT_READY."""
+        ctx = self.ctx
+        if getattr(ctx, "handle", None):
+            for bid in self.blas_ids:
+                ctx.lib.pt_release_bottom_level(ctx.handle, bid)
+        self.blas_ids = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _geometry_descs(self, node_index):
+        """D3D12_RAYTRACING_GEOMETRY_DESC per mesh of a mesh node + the build flags of Scene.ixx:320-329: OPAQUE iff the mesh
+        has no material or AlphaMode::Opaque; skeletal mesh nodes are built PREFER_FAST_BUILD | ALLOW_UPDATE, static ones
+        PREFER_FAST_TRACE."""
+        scene = self.desc
+        first, count = scene.blas[node_index]
+        geoms = (GeometryDesc * max(1, count))()
+        skeletal = False
+        for g in range(count):
+            mesh, hv, hi = scene.geometry[first + g]
+            d = geoms[g]
+            d.VertexBuffer = self._heap_dev[hv].data_ptr()
+            d.VertexCount, d.VertexStride = len(mesh.vertices), mesh.vertices.dtype.itemsize
+            d.IndexBuffer = self._heap_dev[hi].data_ptr()
+            d.IndexCount, d.IndexStride = mesh.indices.size, mesh.indices.dtype.itemsize
+            alpha_mode = int(mesh.material["AlphaMode"]) if mesh.material is not None else 0
+            d.Flags = 1 if alpha_mode == 0 else 0
+            skeletal = skeletal or getattr(mesh, "skeletal_vertices", None) is not None
+        return geoms, count, (0x8 | 0x1) if skeletal else 0x4
+
     def SkinSkeletalMeshes(self, mesh, skeletal_transforms):
         """Scene::SkinSkeletalMeshes (Source/Scene.ixx:233-280) for one mesh: joint transforms -> SkeletalMeshSkinning."""
         ctx, lib = self.ctx, self.ctx.lib
@@ -256,16 +307,9 @@ class Scene:
 
     def UpdateAccelerationStructures(self, node_index):
         """the PERFORM_UPDATE branch of Scene::CreateAccelerationStructures (Source/Scene.ixx:327-345) + TLAS rebuild."""
-        ctx, scene, lib = self.ctx, self.desc, self.ctx.lib
-        first, count = scene.blas[node_index]
-        geoms = (GeometryDesc * max(1, count))()
-        for g in range(count):
-            mesh, hv, hi = scene.geometry[first + g]
-            d = geoms[g]
-            d.VertexBuffer = self._heap_dev[hv].data_ptr(); d.VertexCount, d.VertexStride = len(mesh.vertices), mesh.vertices.dtype.itemsize
-            d.IndexBuffer = self._heap_dev[hi].data_ptr(); d.IndexCount, d.IndexStride = mesh.indices.size, mesh.indices.dtype.itemsize
-            d.Flags = 1
-        ctx.check(lib.pt_update_bottom_level(ctx.handle, self.blas_ids[node_index], C.addressof(geoms), count, 0x9))
+        ctx, lib = self.ctx, self.ctx.lib
+        geoms, count, flags = self._geometry_descs(node_index)
+        ctx.check(lib.pt_update_bottom_level(ctx.handle, self.blas_ids[node_index], C.addressof(geoms), count, flags))
         self._build_top_level()
 
     def download(self, heap_index, dtype):
@@ -277,19 +321,10 @@ class Scene:
         for bid in self.blas_ids:
             ctx.check(lib.pt_release_bottom_level(ctx.handle, bid))
         self.blas_ids = []
-        for first, count in scene.blas:                       # one BLAS per MeshNode, one geometry per Mesh
-            geoms = (GeometryDesc * max(1, count))()
-            for g in range(count):
-                mesh, hv, hi = scene.geometry[first + g]
-                d = geoms[g]
-                d.VertexBuffer = self._heap_dev[hv].data_ptr()
-                d.VertexCount, d.VertexStride = len(mesh.vertices), mesh.vertices.dtype.itemsize
-                d.IndexBuffer = self._heap_dev[hi].data_ptr()
-                d.IndexCount, d.IndexStride = mesh.indices.size, mesh.indices.dtype.itemsize
-                alpha_mode = int(mesh.material["AlphaMode"]) if mesh.material is not None else 0
-                d.Flags = 1 if alpha_mode == 0 else 0             # OPAQUE iff AlphaMode::Opaque or no material (Scene.ixx:320-324)
+        for node_index in range(len(scene.blas)):             # one BLAS per MeshNode, one geometry per Mesh
+            geoms, count, flags = self._geometry_descs(node_index)
             bid = C.c_uint64(0)
-            ctx.check(lib.pt_build_bottom_level(ctx.handle, C.addressof(geoms), count, 0x4, C.byref(bid)))
+            ctx.check(lib.pt_build_bottom_level(ctx.handle, C.addressof(geoms), count, flags, C.byref(bid)))
             self.blas_ids.append(bid.value)
         self._build_top_level()
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTAMD_ABI_VERSION 1
+#define PTAMD_ABI_VERSION 2
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -208,13 +208,19 @@ typedef struct PtGeometryDesc {           /* D3D12_RAYTRACING_GEOMETRY_DESC as f
 
 /* Bottom level: one per MeshNode, one geometry per Mesh (Source/Scene.ixx:286-341 ->
  * CommandList::BuildAccelerationStructures, Source/CommandList.ixx:217-233). Returns an id
- * (reference: RTXMU accel-struct id). The LBVH is built on the device, on the context stream. */
+ * (reference: RTXMU accel-struct id). A compressed 8-wide BVH is built on the device, on the context stream (Morton order,
+ * binary hierarchy, surface-area-greedy collapse, 8-bit child boxes); the call returns when it is built. With
+ * PT_BUILD_FLAG_ALLOW_UPDATE (the reference sets it for skeletal meshes, Scene.ixx:329) the structure keeps what a refit needs. */
 int  pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint32_t geometry_count,
                            uint32_t build_flags, uint64_t* out_blas_id);
 /* D3D12_RAYTRACING_ACCELERATION_STRUCTURE_BUILD_FLAG_PERFORM_UPDATE for a skinned mesh node (Source/Scene.ixx:327-341,
  * CommandList::UpdateAccelerationStructures, Source/CommandList.ixx:235-241): same id, geometry re-read from the (moved)
- * vertex buffers. Call pt_build_top_level afterwards, as Scene::CreateAccelerationStructures does every dynamic frame. */
+ * vertex buffers. A structure built with PT_BUILD_FLAG_ALLOW_UPDATE and given the same triangle counts is REFITTED in place
+ * (asynchronous: no allocation, no wait); any other is rebuilt under its id. Until pt_build_top_level has been called again
+ * (Scene::CreateAccelerationStructures does so every dynamic frame) renders answer PT_ERROR_NOT_READY. */
 int  pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDesc* geometries, uint32_t geometry_count, uint32_t build_flags);
+/* Frees a bottom level. If the live top level refers to it, that top level is dropped with it (renders answer
+ * PT_ERROR_NOT_READY until the next pt_build_top_level). */
 int  pt_release_bottom_level(PtContext* ctx, uint64_t blas_id);
 
 /* SkeletalMeshSkinning::Process (Source/SkeletalMeshSkinning.ixx:38-57 -> Shaders/SkeletalMeshSkinning.hlsl:28-62).
@@ -232,14 +238,19 @@ typedef struct PtInstanceDesc {           /* D3D12_RAYTRACING_INSTANCE_DESC as f
 } PtInstanceDesc;
 
 /* Top level over all mesh-node instances (BuildTopLevelAccelerationStructure,
- * Source/RaytracingHelpers.ixx:28-74). descs is HOST memory. Rebuilds if one already exists. */
+ * Source/RaytracingHelpers.ixx:28-74). descs is HOST memory, copied before the call returns. Rebuilds if one already exists.
+ * Enqueued on the stream like the reference's build on its command list: instance records, the 8-wide tree over the instance
+ * boxes and the traversal copy are made by kernels; a rebuild that needs no more room than the last one allocates nothing and
+ * waits for nothing. A tree too deep for the traversal stack is reported by the next pt_sync / render call. */
 int  pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t count, uint32_t build_flags);
 
 typedef struct PtAccelStats {
     uint32_t InstanceCount, BottomLevelCount;
     uint64_t TriangleCount;               /* sum over instances */
     uint64_t NodeBytes, TriangleBytes;    /* device memory held by BVH nodes / triangle packets */
-    uint32_t NodeSizeBytes, TriangleSizeBytes;
+    uint32_t NodeSizeBytes, TriangleSizeBytes;   /* 80 (compressed 8-wide node) / 48 */
+    uint32_t MaxBottomLevelDepth, TopLevelDepth; /* levels of 8-wide nodes */
+    uint64_t BlobBytes;                   /* the traversal copy: instances + every referenced bottom level + top level */
 } PtAccelStats;
 int  pt_get_accel_stats(PtContext* ctx, PtAccelStats* out);           /* synchronises */
 
@@ -305,8 +316,9 @@ typedef struct PtCounters {
     uint64_t NodesVisited;        /* BVH node fetches   (only with PT_DEBUG_TRAVERSAL_STATS) */
     uint64_t TrianglesTested;     /* triangle tests     (only with PT_DEBUG_TRAVERSAL_STATS) */
     uint64_t WavefrontIterations; /* extend/shade rounds launched by the last pt_raytrace_render */
-    uint64_t BvhMismatches;       /* PT_DEBUG_BRUTE_FORCE: rays whose LBVH result differed from brute force (must be 0) */
-    uint64_t _reserved[2];
+    uint64_t BvhMismatches;       /* PT_DEBUG_BRUTE_FORCE: rays whose BVH result differed from brute force (must be 0) */
+    uint64_t StackOverflows;      /* traversal-stack pushes refused for lack of room (must be 0: the builders reject structures that are too deep) */
+    uint64_t _reserved[1];
 } PtCounters;
 int  pt_reset_counters(PtContext* ctx);
 int  pt_get_counters(PtContext* ctx, PtCounters* out);
@@ -318,6 +330,19 @@ int  pt_get_counters(PtContext* ctx, PtCounters* out);
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
 int  pt_debug_read_mismatch(PtContext* ctx, float* out16);
+
+/* Developer / test aid: the traversal copy of the scene (instances, 8-wide nodes of the top level and of every referenced
+ * bottom level, triangle packets in node order, instance order list) copied to host memory, with its section offsets in 16-byte
+ * units. tests/ decode it to check the structural invariants of the builder (containment, reference ranges, depth). Synchronises. */
+typedef struct PtBlobLayout {
+    uint32_t InstanceOffset16, NodeOffset16, TriangleOffset16, OrderOffset16;
+    uint32_t InstanceCount, NodeCount, TriangleCount, Bytes;
+} PtBlobLayout;
+int  pt_debug_download_blob(PtContext* ctx, void* host_dst, uint64_t capacity_bytes, PtBlobLayout* out_layout);
+/* Developer aid: one closest-hit ray through the one-lane two-level walk with a step log of (code, a, b, stack depth) words:
+ * 1 enter instance a | 2 triangle b of instance a | 3 node group (a, b) about to be visited | 4 groups after the visit |
+ * 5 popped (a, b) | 6 top-level state restored | 7 result (instance, triangle slot). Synchronises. */
+int  pt_debug_trace_ray(PtContext* ctx, const PtRayDesc* host_ray, uint32_t* host_log, uint32_t log_words);
 
 /* Per-kernel timing with HIP events recorded on the context stream around every extend / shade launch
  * issued after pt_enable_kernel_timing(ctx, 1); the getter synchronises and returns the sums since then. */

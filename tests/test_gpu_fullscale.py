@@ -1,0 +1,152 @@
+"""GPU tests (-m gpu) of the three big BASELINE.json configs AT THEIR REAL SCALE, against the oracle:
+
+  C3  Sponza-scale mesh, 250 632 triangles in one BLAS, 1920x1080, 1 spp, 8 bounces + Russian roulette
+  C5  10 000 instances of a 320-triangle mesh (two-level BVH) + ground + light, 1920x1080, 4 spp, 8 bounces
+  C4  Cornell box 3840x2160, 16 spp, 16 bounces, as one rank-of-8 shard and as the whole frame
+
+The oracle cannot render a full frame of these in test time, so each test renders one horizontal band with the oracle (its own
+BVH: an independent builder and traversal) and compares it with (a) the same band rendered by the GPU alone -- a sharding with as
+many ranks as bands gives a context exactly those rows, and with them the ray count of the band -- and (b) the same rows of the
+full-frame GPU render. G-buffer: bit for bit. Radiance: bit for bit where the arithmetic is pinned (constant environment), per-pixel
+L2 < 1e-3 (north_star) where the procedural sky goes through powf. Every test also asserts that no traversal-stack push was
+refused, and the structural invariants of the built BVH (tests/bvh_check.py)."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+import bvh_check
+from test_gpu_parity import GB_KEYS, L2_TOLERANCE, SKY_ABS_TOLERANCE, gpu_render
+
+pytestmark = pytest.mark.gpu
+
+
+def leaf_rule(n):            # pt_trace.hpp blas_leaf_tris
+    return 2 if n <= 32 else 1
+
+
+def oracle_band(oracle, L, scene, gs, W, H, y0, y1):
+    """rows [y0, y1) of the frame by the oracle: (G-buffer dict incl. Radiance, rays traced in the band, RadianceF32)."""
+    gb = {k: np.zeros((H, W, c), dt) for k, (dt, c) in L.GBUFFER_FORMATS.items()}
+    gb.update({k: np.zeros((H, W, c), dt) for k, (dt, c) in L.DENOISER_FORMATS.items()})
+    consts = np.zeros((), L.GBUFFER_CONSTANTS)
+    consts["RenderSize"] = (W, H); consts["Flags"] = L.GBufferFlags.DefaultNoDenoiser
+    osc = oracle.OracleScene(scene, accel_mode=1)
+    rays = osc.gbuffer(consts, gb, rows=(y0, y1))
+    f32 = np.zeros((H, W, 4), np.float32)
+    rays += osc.raytrace(gs, gb, rows=(y0, y1), radiance_f32=f32)
+    osc.close()
+    return {k: v[y0:y1] for k, v in gb.items()}, rays, f32[y0:y1]
+
+
+def check_band(out, ref_gb, ref_f32, exact):
+    for k in GB_KEYS:
+        a, b = out[k], ref_gb[k]
+        if a.dtype.kind == "f":
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        assert np.array_equal(a, b), f"G-buffer texture {k} differs from the oracle"
+    st = ge.compare_radiance(out["RadianceF32"], ref_f32)
+    assert st["rms"] < L2_TOLERANCE, st
+    if exact:
+        assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32)), st
+        assert np.array_equal(out["Radiance"], ref_gb["Radiance"])
+    else:
+        assert st["max"] < SKY_ABS_TOLERANCE * 50, st        # sky radiance times throughput: powf differs in the last ulp
+
+
+def check_structure(ctx, expect_instances, expect_triangles):
+    lay, buf = ctx.download_blob()
+    st = bvh_check.check_blob(lay, buf, leaf_rule)
+    acc = ctx.accel_stats()
+    assert st["instances"] == expect_instances == acc.InstanceCount
+    assert acc.TriangleCount == expect_triangles
+    assert st["blas_depth"] == acc.MaxBottomLevelDepth and st["tlas_depth"] == acc.TopLevelDepth
+    assert st["tlas_depth"] + st["blas_depth"] + 4 <= 64          # kStackSize
+    return st, acc
+
+
+def full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band, band_index, exact):
+    world = (H + band - 1) // band
+    y0, y1 = band_index * band, min(H, (band_index + 1) * band)
+    full, cf = gpu_render(ptamd, gpu, scene, gs, W, H)
+    assert cf.StackOverflows == 0
+    assert cf.PrimaryRays == W * H
+    spp, bounces = int(gs["SamplesPerPixel"]), int(gs["Bounces"])
+    assert W * H < cf.PrimaryRays + cf.SecondaryRays <= W * H * (1 + spp * bounces)
+    rad = full["RadianceF32"][..., :3]
+    hit = np.isfinite(full["Position"][..., 3])              # a primary miss keeps the G-buffer's environment colour (Raytracing.hlsl:241-252)
+    assert hit.any() and np.isfinite(rad).all() and (rad >= 0).all()
+    assert np.array_equal(full["Radiance"][..., :3][hit], rad.astype(np.float16).view(np.uint16)[hit])
+    part, cp = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(band_index, world, band))     # exactly rows [y0, y1)
+    assert cp.StackOverflows == 0 and part["Radiance"].shape[0] == y1 - y0
+    for k in GB_KEYS + ("Radiance",):
+        assert np.array_equal(part[k], full[k][y0:y1]), f"{k}: the band rendered alone differs from the same rows of the full frame"
+    ref_gb, ref_rays, ref_f32 = oracle_band(oracle, L, scene, gs, W, H, y0, y1)
+    assert cp.PrimaryRays + cp.SecondaryRays == ref_rays                                       # identical path structure in the band
+    check_band(part, ref_gb, ref_f32, exact)
+    return full, cf
+
+
+def test_c3_sponza_scale_250k_triangles_1080p(gpu, ptamd, oracle, pkg):
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 1920, 1080
+    scene = S.sponza_scale(aspect=W / H)                       # n_side = 354: 250 632 triangles, 24 materials, ONE bottom level
+    assert scene.triangle_count == 250634
+    gs = S.graphics_settings(W, H, spp=1, bounces=8)
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=24, band_index=27, exact=False)
+    # second band, near the bottom of the frame (the floor right under the camera: long thin triangles, grazing rays), constant
+    # environment: bit-pinned arithmetic
+    scene.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=24, band_index=41, exact=True)
+    # structure of what was built (the context still holds the last scene's structures until the next build)
+    g = ptamd.Scene(gpu, scene)
+    st, acc = check_structure(gpu, 2, 250634)
+    assert acc.NodeSizeBytes == 80 and st["blas_nodes"] * 80 < 12e6           # compressed wide nodes: a fraction of the 16 MB of a binary fp32 tree
+    g.close()
+
+
+def test_c5_ten_thousand_instances_1080p(gpu, ptamd, oracle, pkg):
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 1920, 1080
+    scene = S.instanced_grid(n=100, aspect=W / H)
+    assert len(scene.objects) == 10002
+    gs = S.graphics_settings(W, H, spp=4, bounces=8)
+    full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=16, band_index=40, exact=False)
+    scene.scene_data = S.make_scene_data((0.3, 0.3, 0.35, 1.0))
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=16, band_index=30, exact=True)
+    g = ptamd.Scene(gpu, scene)
+    check_structure(gpu, 10002, 10000 * 320 + 4)
+    g.close()
+    # the 8-rank assembly of the frame (simulated ranks on one GPU) is the 1-GPU frame
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    pieces, rays = [], 0
+    for r in range(8):
+        o, c = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(r, 8, 16))
+        assert c.StackOverflows == 0
+        pieces.append(o["Radiance"]); rays += c.PrimaryRays + c.SecondaryRays
+    assert np.array_equal(SH.deinterleave(pieces, H, 16), full["Radiance"])
+    assert rays == cf.PrimaryRays + cf.SecondaryRays
+
+
+def test_c4_cornell_4k_16spp_16_bounces(gpu, ptamd, oracle, pkg):
+    S, L = pkg.scenes, pkg.layouts
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    W, H = 3840, 2160
+    scene = S.cornell_box(aspect=W / H, variant="ggx")
+    gs = S.graphics_settings(W, H, spp=16, bounces=16)
+    # whole frame on one GPU: 8.3 M paths in the queues
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=16, band_index=67, exact=True)
+    assert 0.05 < full["RadianceF32"][..., :3].mean() < 5.0
+    # the configuration's own sharding: rank 3 of 8, 16-row bands. Its rows against the full frame, one of its bands against the oracle
+    part, cp = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(3, 8, 16))
+    assert cp.StackOverflows == 0
+    assert np.array_equal(part["Radiance"], SH.extract_local(full["Radiance"], 3, 8, 16))
+    b = 3 + 8 * 9                                             # the 10th band of rank 3: rows 1200..1216
+    ref_gb, ref_rays, ref_f32 = oracle_band(oracle, L, scene, gs, W, H, b * 16, b * 16 + 16)
+    local = SH.rank_bands(H, 3, 8, 16)[9][2]
+    assert np.array_equal(part["RadianceF32"][local:local + 16].view(np.uint32), ref_f32.view(np.uint32))
+    assert np.array_equal(part["Radiance"][local:local + 16], ref_gb["Radiance"])
+    # determinism at this size
+    again, ca = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(3, 8, 16))
+    assert np.array_equal(again["Radiance"], part["Radiance"]) and ca.SecondaryRays == cp.SecondaryRays
