@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
 // dealt to sub-queue t % kSubQueues, a path never leaves its sub-queue, so a segment can never overflow and
 // every sub-queue samples the whole image (balanced). One atomic per 256-thread block and tile.
 constexpr uint32_t kSubQueues = 32;
+constexpr uint32_t kCountStride = 3u * kSubQueues;      // per round: entries traced | fresh | cursor of the streaming form, one word per sub-queue
 
 // block-wide stream compaction: wave64 ballot + prefix popcount inside each wave, wave totals through LDS,
 // ONE atomicAdd per block. Every thread of the block must call it. lds: 8 words.
@@ -790,6 +791,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming round for scenes whose blob lives in HBM / L2 (C3: one 250 k-triangle BLAS, C5: 10 k instances).
+// The lock-step forms above trace one tile of rays per wave and wait for the slowest lane: on incoherent bounce rays in a big
+// BVH (8..60 node visits per ray) a wave spent 8 of 9 issue slots on idle lanes (PMC, profiles/r02_b_c3: 540 VALU
+// wave-instructions per ray against ~66 at full lanes). Here a wave is a set of 64 persistent traversal lanes:
+//   refill   idle lanes take the next rays of the sub-queue (one atomic on the sub-queue's cursor per refill, consecutive
+//            entries for consecutive idle lanes: coalesced reads) -- a lane that finishes early does not wait for its neighbours
+//   walk     kStreamSteps steps of the one-ray two-level walk (trace_single's state machine, one stack per lane in LDS)
+//   harvest  finished lanes append (queue entry, hit) to the wave's done list in LDS
+//   shade    whenever 64 hits are waiting the whole wave shades them, full lanes, with the same shade_traced / scatter
+//            as every other form, and emits survivors with one atomic per wave and region
+// The four waves of a block run independently (no barrier) until the fresh tiles. Same arithmetic, same tie-break: the image is
+// bit-identical to the other schedules (tests/test_gpu_parity.py::test_traversal_schedules_agree).
+constexpr int kStreamStackLds = 6;
+constexpr uint32_t kStreamSteps = 6;                    // walk steps between two harvests
+constexpr uint32_t kStreamRefillMin = 12;               // idle lanes worth a refill
+constexpr uint32_t kStreamDone = 128;                   // done-list entries per wave
+constexpr uint32_t kStreamLdsStack = (uint32_t)kStreamStackLds * 256u * 8u;
+constexpr uint32_t kStreamLdsRays = 256u * 32u;
+constexpr uint32_t kStreamLdsWave = kStreamDone * 16u + kStreamDone * 4u + kStreamDone * 4u;      // hit t u v slot | instance | queue entry
+constexpr uint32_t kStreamLds = kStreamLdsStack + kStreamLdsRays + 4u * kStreamLdsWave;
+
+// wave-level twin of block_reserve2: two compactions, two returning atomics issued by two different lanes
+PT_DEV void wave_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t& slotA, uint32_t& slotB)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
+    uint32_t base = 0;
+    if (lane == 0 && na) base = atomicAdd(counterA, na);
+    if (lane == 1 && nb) base = atomicAdd(counterB, nb);
+    slotA = (uint32_t)__shfl((int)base, 0) + (uint32_t)__popcll(ma & lt);
+    slotB = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & lt);
+}
+
+template <bool TEXTURED, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_stream(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
+                                               BlobView bv, PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* cursorIn,
+                                               uint32_t* countOut, DeviceCounters* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t lds[16];
+    const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
+    const uint32_t seg = sq * segCap;
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+
+    if (nT) {
+        BlobReader<false> blob; blob.p = bv.base;
+        AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+        uint2 spill[kStackSize - kStreamStackLds];
+        GroupStack<kStreamStackLds> stack; stack.init((uint2*)smem, spill);
+        f4v* worldRay = (f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;                 // o.xyz tmin | d.xyz tmax of the lane's ray
+        unsigned char* mine = smem + kStreamLdsStack + kStreamLdsRays + wave * kStreamLdsWave;
+        f4v* doneHit = (f4v*)mine;                                                       // t u v slot
+        uint32_t* doneInst = (uint32_t*)(mine + kStreamDone * 16u);
+        uint32_t* doneEntry = (uint32_t*)(mine + kStreamDone * 20u);
+        constexpr uint32_t kMarker = 0xFFFFFFFFu;
+        TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
+
+        // lane state. qi: queue entry of the ray in flight (~0u: idle). curInst == ~0u: the walk is in the top level.
+        uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0;
+        float tmin = 0.0f;
+        BoxRay br; br.o = V3(0, 0, 0); br.idir = V3(1, 1, 1); br.octinv4 = 0;
+        RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+        Hit h; h.t = 0.0f; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
+        uint2 G = make_uint2(0u, 0u), T = make_uint2(0u, 0u);
+        uint32_t nDone = 0;                                      // wave-uniform
+        bool exhausted = false;                                  // wave-uniform: the sub-queue has no ray left to hand out
+        const bool oneInstance = bv.instCount == 1u;
+
+        while (true) {
+            // ---- shade: 64 waiting hits (or the rest, once nothing is in flight any more)
+            const unsigned long long busy = __ballot(qi != ~0u);
+            if (nDone >= 64u || (exhausted && !busy && nDone)) {
+                const uint32_t count = nDone < 64u ? nDone : 64u, first = nDone - count;
+                bool toTraced = false, toFresh = false;
+                PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+                if (lane < count) {
+                    const uint32_t e = doneEntry[first + lane];
+                    const f4v q = doneHit[first + lane];
+                    const uint32_t inst = doneInst[first + lane];
+                    p = load_path(qin, seg + e);
+                    const float4 d = qin.r1[seg + e];
+                    shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv }, sd, gs, tx, aux, p, make_uint4(inst, __float_as_uint(q.w), __float_as_uint(q.y), __float_as_uint(q.z)),
+                                           q.x, V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD);
+                }
+                uint32_t slotT, slotF;
+                wave_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], slotT, slotF);
+                if (toTraced) {
+                    store_path(qout, seg + slotT, p);
+                    qout.r0[seg + slotT] = make_float4(newO.x, newO.y, newO.z, 0.0f);
+                    qout.r1[seg + slotT] = make_float4(newD.x, newD.y, newD.z, INFINITY);
+                }
+                if (toFresh) store_path(qout, seg + (segCap - 1u - slotF), p);
+                nDone = first;
+                if (exhausted && !busy && !nDone) break;
+                continue;
+            }
+            if (exhausted && !busy) break;                                   // nothing in flight, nothing waiting
+            // ---- refill: idle lanes take the next rays of the sub-queue
+            {
+                const unsigned long long idle = ~busy;
+                const uint32_t nIdle = (uint32_t)__popcll(idle);
+                if (!exhausted && (nIdle >= kStreamRefillMin || !busy)) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&cursorIn[sq], nIdle);
+                    base = (uint32_t)__shfl((int)base, 0);
+                    if (base + nIdle >= nT) exhausted = true;
+                    if (qi == ~0u) {
+                        const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
+                        if (e < nT) {
+                            const float4 o = qin.r0[seg + e], d = qin.r1[seg + e];
+                            worldRay[0] = (f4v){ o.x, o.y, o.z, o.w }; worldRay[1] = (f4v){ d.x, d.y, d.z, d.w };
+                            qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16;
+                            br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                            h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
+                            G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
+                            stack.sp = 0;
+                        }
+                    }
+                }
+            }
+            // ---- walk
+            bool finished = false;
+            #pragma unroll 1
+            for (uint32_t step = 0; step < kStreamSteps; step++) {
+                const bool live = qi != ~0u && !finished;
+                if (live && !T.y && G.y <= 0x00FFFFFFu) {                     // nothing at hand: pop, or the ray is done
+                    if (stack.sp > 0) {
+                        G = stack.pop();
+                        if (G.x == kMarker && G.y == 0u) {                    // leave the BLAS: back to the world-space ray
+                            if (stack.overflow) { finished = true; stack.sp = 0; G = make_uint2(0u, 0u); }
+                            else {
+                                T = stack.pop(); G = stack.pop();
+                                const f4v wo = worldRay[0], wd = worldRay[1];
+                                br = box_ray(V3(wo.x, wo.y, wo.z), V3(wd.x, wd.y, wd.z)); nodeBase16 = bv.nodeOff16; curInst = ~0u;
+                            }
+                        }
+                    } else finished = true;
+                }
+                if (live && !finished && !T.y && G.y > 0x00FFFFFFu)
+                    visit_node<STATS, false>(blob, nodeBase16, br, tmin, h.t, G, T, stack, &st);
+                if (live && !finished && T.y && curInst == ~0u) {             // a TLAS "triangle": enter the instance
+                    const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
+                    T.y &= T.y - 1u;
+                    const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
+                    const uint32_t ia = bv.instOff16 + x * kInst16;
+                    const f4v mk = blob.ld(ia + 5);
+                    const uint32_t ntri = __float_as_uint(mk.y);
+                    if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
+                        const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
+                        const f4v wo = worldRay[0], wd = worldRay[1];
+                        const v3 ro = V3(w0.x * wo.x + w0.y * wo.y + w0.z * wo.z + w0.w, w1.x * wo.x + w1.y * wo.y + w1.z * wo.z + w1.w, w2.x * wo.x + w2.y * wo.y + w2.z * wo.z + w2.w);
+                        const v3 rd = V3(w0.x * wd.x + w0.y * wd.y + w0.z * wd.z, w1.x * wd.x + w1.y * wd.y + w1.z * wd.z, w2.x * wd.x + w2.y * wd.y + w2.z * wd.z);
+                        rs = ray_setup(rd);
+                        br = box_ray(ro, rd);
+                        nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
+                        triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+                        stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
+                        const bool single = blas_single_leaf(ntri);
+                        G = root_node_group(single); T = root_tri_group(single, ntri);
+                        curInst = x;
+                    }
+                }
+                if (live && !finished && T.y && curInst != ~0u) {             // one triangle of the current BLAS
+                    const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
+                    T.y &= T.y - 1u;
+                    const uint32_t ta = triBase16 + i * kTri16;
+                    const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+                    if (STATS) st.tris++;
+                    float t, u, v;
+                    if (tri_test(rs, br.o, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
+                        commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, curInst, __float_as_uint(pa.w), __float_as_uint(pb.w), i);
+                }
+            }
+            // ---- harvest
+            {
+                const unsigned long long fm = __ballot(finished);
+                if (finished) {
+                    const uint32_t e = nDone + (uint32_t)__popcll(fm & ltMask);
+                    const f4v wd = worldRay[1];
+                    const bool hit = h.inst != ~0u && h.t < wd.w;
+                    doneHit[e] = (f4v){ h.t, h.u, h.v, __uint_as_float(h.slot) };
+                    doneInst[e] = hit ? h.inst : ~0u;
+                    doneEntry[e] = qi;
+                    qi = ~0u;
+                }
+                nDone += (uint32_t)__popcll(fm);
+            }
+        }
+        if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+        if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
+    }
+    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
+        const uint32_t local = tile * 256u + threadIdx.x;
+        bool toTraced = false, toFresh = false;
+        PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        if (local < nF) {
+            p = load_path(qin, seg + (segCap - 1u - local));
+            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
+        }
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+    }
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
@@ -989,7 +1200,7 @@ static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if
 // the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
-    const uint32_t cstride = 2u * kSubQueues;                                  // traced + fresh counters per round
+    const uint32_t cstride = kCountStride;                                     // traced + fresh counters + the streaming form's cursor, per round
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
     k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues]);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
@@ -998,6 +1209,21 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
         const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
+        // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
+        const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+        if (!lds && !(c.debugFlags & lockStep)) {
+            for (uint32_t r = 0; r <= rounds; r++) {
+                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
+                timing_begin(c, c.evRound, c.nRound);
+                #define PT_STREAM(T, S) k_round_stream<T, S><<<grid, 256, kStreamLds, c.stream>>>(sv, fv, c.frameConstants, tx, c.blob, qin, qout, aux, segCap, cin, cin + 2u * kSubQueues, cout, c.counters)
+                if (c.heapHasTextures) { if (stats) PT_STREAM(true, true); else PT_STREAM(true, false); }
+                else { if (stats) PT_STREAM(false, true); else PT_STREAM(false, false); }
+                #undef PT_STREAM
+                timing_end(c, c.evRound, c.nRound); c.nRound++;
+            }
+            return hipGetLastError();
+        }
         // fused rounds: everything except the validation / statistics variants, which keep the two-kernel form
         const uint32_t pairOnly = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
         if (!(c.debugFlags & pairOnly)) {
@@ -1063,7 +1289,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     const uint32_t rounds = gs.SamplesPerPixel * (gs.Bounces + 1u);
     const uint32_t tiles = (npix + 255u) / 256u;
     const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
-    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * 2u * kSubQueues);
+    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * kCountStride);
     if (e != hipSuccess) return e;
     if (!c.frameConstants && (e = hipMalloc((void**)&c.frameConstants, sizeof(FrameConstants))) != hipSuccess) return e;
     if (gs.Denoiser != PT_DENOISER_NONE && npix > c.pixelAuxCapacity) {
@@ -1073,7 +1299,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         c.pixelAuxCapacity = npix;
     }
     FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
-    k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * 2u * kSubQueues);
+    k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * kCountStride);
     // persistent grid, but never more blocks than the queue has tiles: surplus blocks only cost dispatch slots and LDS that
     // a concurrent frame's kernels (other streams) could use -- this matters for small shards (1/8 of a 1080p frame = 1013 tiles)
     const uint32_t grid = std::min(persistent_grid(c.device), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
@@ -1081,7 +1307,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
     const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
-                           (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED)) == 0;   // counters / validation variants launch directly
+                           (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP)) == 0;   // counters / validation variants launch directly
     if (graphable) {
         std::string key;
         key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);

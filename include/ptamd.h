@@ -326,6 +326,7 @@ int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_TRAVERSAL_V1   0x4u     /* bounce rays use the interleaved TLAS/BLAS traversal of k_gbuffer instead of the phase-aligned one */
 #define PT_DEBUG_TRAVERSAL_PHASED 0x8u  /* bounce rays: the TLAS-walking phase-aligned schedule even when the scene is small enough for the flat one */
 #define PT_DEBUG_UNFUSED_ROUNDS  0x10u    /* a round = k_shade + k_extend2 (two launches, hit records through HBM) instead of the fused k_round */
+#define PT_DEBUG_LOCKSTEP        0x20u    /* scenes too large for LDS: the lock-step schedules (one tile of rays per wave) instead of the streaming form */
 #define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */

@@ -312,6 +312,35 @@ def test_traversal_schedules_agree(gpu, ptamd, pkg):
             assert rays == results[0][1] and np.array_equal(img, results[0][0])
 
 
+def test_streaming_and_lockstep_schedules_agree(gpu, ptamd, pkg):
+    """Scenes whose traversal copy does not fit LDS take the streaming form of a round by default (persistent traversal lanes that
+    pull rays from the sub-queue and hand hits to a batched shade); PT_DEBUG_LOCKSTEP (flat or phased schedule, by instance count),
+    _PHASED, _V1 and the two-kernel form are the same arithmetic on other schedules: images and ray counts identical bit for bit,
+    with and without the traversal statistics variant."""
+    S = pkg.scenes
+    W, H = 128, 80
+    scenes = [S.sponza_scale(n_side=48, aspect=W / H),                     # 2 instances, one 4.6 k-triangle BLAS: flat when lock-step
+              S.instanced_grid(n=24, aspect=W / H)]                        # 578 instances: phased when lock-step
+    for scene in scenes:
+        scene.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+        gs = S.graphics_settings(W, H, spp=3, bounces=7, frame_index=2)
+        results = []
+        for flags in (0, 0x20, 8, 4, 0x10, 1, 0x21):
+            gpu.set_sharding(0, 1, 16)
+            g = ptamd.Scene(gpu, scene)
+            r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
+            gpu.set_debug_flags(flags); gpu.reset_counters()
+            r.render(gs); gpu.sync()
+            c = gpu.counters()
+            assert c.StackOverflows == 0
+            if flags & 1:
+                assert c.NodesVisited > 0 and c.TrianglesTested > 0
+            results.append((ptamd.textures_to_numpy(r.textures)["RadianceF32"].view(np.uint32).copy(), c.SecondaryRays))
+            gpu.set_debug_flags(0)
+        for img, rays in results[1:]:
+            assert rays == results[0][1] and np.array_equal(img, results[0][0])
+
+
 def test_deterministic_and_sharding_invariant(gpu, ptamd, pkg):
     """Run twice: bit-identical. Render as rank r of 3 and of 8: the assembled frame equals the unsharded one
     (RNG seeds and camera rays use global pixel coordinates)."""
