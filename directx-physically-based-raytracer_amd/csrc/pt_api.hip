@@ -178,10 +178,11 @@ static int check_geometries(Context& c, const PtGeometryDesc* geometries, uint32
 
 static void drop_tlas(Context& c) { c.haveTlas = false; c.tlasBlasIds.clear(); }
 
-// the traversal stack holds one entry per level of both trees plus the three of an instance transition (pt_trace.hpp)
+// the traversal stack holds at most two entries per level of both trees (a node group and, in the streaming form, a postponed
+// leaf group) plus the three of an instance transition (pt_trace.hpp)
 static int check_depth(Context& c, uint32_t tlasDepth)
 {
-    if (tlasDepth + c.maxBlasDepth + 4u > (uint32_t)kStackSize)
+    if (2u * (tlasDepth + c.maxBlasDepth) + 4u > (uint32_t)kStackSize)
         return fail(&c, PT_ERROR_INVALID_ARGUMENT, "acceleration structure too deep for the traversal stack (top level " + std::to_string(tlasDepth)
                     + " + bottom level " + std::to_string(c.maxBlasDepth) + " levels)");
     return PT_OK;
@@ -211,7 +212,7 @@ int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint
     Blas b;
     hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0, c.stream, b);
     if (e != hipSuccess) { free_blas(b); return fail_hip(&c, e, "bottom-level build"); }
-    if (b.buildError || b.depth + 4u > (uint32_t)kStackSize) { free_blas(b); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level build failed: tree too deep for the traversal stack"); }
+    if (b.buildError || 2u * b.depth + 4u > (uint32_t)kStackSize) { free_blas(b); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level build failed: tree too deep for the traversal stack"); }
     b.geometryCount = geometry_count;
     uint64_t id = c.nextBlasId++;
     c.blas[id] = b;
@@ -246,7 +247,7 @@ int pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDes
     Blas nb;
     hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0 || b.updatable, c.stream, nb);
     if (e != hipSuccess) { free_blas(nb); return fail_hip(&c, e, "bottom-level update"); }
-    if (nb.buildError || nb.depth + 4u > (uint32_t)kStackSize) { free_blas(nb); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level update failed: tree too deep for the traversal stack"); }
+    if (nb.buildError || 2u * nb.depth + 4u > (uint32_t)kStackSize) { free_blas(nb); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level update failed: tree too deep for the traversal stack"); }
     nb.geometryCount = geometry_count;
     free_blas(b);
     b = nb;

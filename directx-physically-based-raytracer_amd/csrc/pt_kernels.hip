@@ -84,7 +84,7 @@ PT_DEV AlphaContext alpha_context(const SceneView& sv)
 
 PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)      // MeshHelpers.hlsli:5-9 (typed R16/R32 buffer)
 {
-    return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
+    return stride == 2 ? (uint32_t)gptr<uint16_t>(ib)[i] : gptr<uint32_t>(ib)[i];
 }
 
 // Hit reconstruction half of CastRay (Shaders/RaytracingHelpers.hlsli:73-131) + HitInfo::Initialize
@@ -146,7 +146,7 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
         #pragma unroll
         for (int k = 0; k < 3; k++) {
             uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
-            const int16_t* q = (const int16_t*)((const uint8_t*)vb.ptr + (size_t)stride * idx + nOff);
+            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + nOff);
             nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
         v3 n = (nrm[0] + (nrm[1] - nrm[0]) * bu) + (nrm[2] - nrm[0]) * bv;          // Vertex::Interpolate, Vertex.hlsli:63-72
@@ -170,7 +170,7 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
         #pragma unroll
         for (int k = 0; k < 3; k++) {
             uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
-            const int16_t* q = (const int16_t*)((const uint8_t*)vb.ptr + (size_t)stride * idx + tOff);
+            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + tOff);
             tg[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
         const v3 t = (tg[0] + (tg[1] - tg[0]) * bu) + (tg[2] - tg[0]) * bv;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
     if constexpr (MODE == 0) {
         __shared__ uint2 ldsStack[kLdsStackDepth * 256];
         uint2 spill[kStackSize - kLdsStackDepth];
-        GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+        GroupStack<kLdsStackDepth> stack; stack.init((PT_LDS_AS void*)ldsStack, spill);
         BlobReader<false> blob; blob.p = bv.base;
         hit = trace_single<STATS, false, false>(blob, bv, alpha_context(sv), ray.o, ray.d, ray.tmin, ray.tmax, stack, &st, nullptr);
         if (hit.inst != ~0u) hg = load_hit_geometry<false>(blob, bv, hit.inst, hit.slot);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
         unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 8u + (threadIdx.x >> 6) * kFlatWaveLds;
         // pixels outside the frame carry an empty ray interval: they hit nothing but their lanes still serve work items
         hit = trace_closest_flat<STATS, LDS>(blob, bv, alpha_context(sv), ray.o, ray.d, valid ? ray.tmin : 1.0f, valid ? ray.tmax : 0.0f,
-                                             (uint2*)smem, ldsWave, &st);
+                                             (PT_LDS_AS void*)smem, ldsWave, &st);
         if (!valid) return;
         if (hit.inst != ~0u) hg = load_hit_geometry<LDS>(blob, bv, hit.inst, hit.slot);
     }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
                     const float* P = sv.instanceData[h.InstanceIndex].PreviousObjectToWorld; v3 q = h.ObjectPosition;
                     const PtMeshDescriptors md = sv.objects[h.ObjectIndex].MeshDescriptors;
                     if (md.MotionVectors != ~0u) {              // :73-84, StructuredBuffer<float16_t4>
-                        const uint16_t* mvb = (const uint16_t*)sv.heap[md.MotionVectors].ptr;
+                        const PT_GLOBAL_AS uint16_t* mvb = gptr<uint16_t>(sv.heap[md.MotionVectors].ptr);
                         const HeapEntry ib = sv.heap[md.Indices];
                         v3 m3[3];
                         for (int kk = 0; kk < 3; kk++) {
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, BlobView bv,
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
     uint2 spill[kStackSize - kLdsStackDepth];
-    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    GroupStack<kLdsStackDepth> stack; stack.init((PT_LDS_AS void*)ldsStack, spill);
     BlobReader<false> blob; blob.p = bv.base;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     if (bq * 256u >= n) return;                                   // block-uniform: nothing to do, skip the staging
-    uint2* ldsStack = (uint2*)smem;
+    PT_LDS_AS void* ldsStack = (PT_LDS_AS void*)smem;
     BlobReader<LDS> blob;
     if constexpr (LDS) {
         f4v* dst = (f4v*)(smem + kFixed);
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
 
     if (bq * 256u < nT) {                                        // block-uniform
-        uint2* ldsStack = (uint2*)smem;
+        PT_LDS_AS void* ldsStack = (PT_LDS_AS void*)smem;
         BlobReader<LDS> blob;
         if constexpr (LDS) {
             f4v* dst = (f4v*)(smem + kFixed);
@@ -804,9 +804,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //            as every other form, and emits survivors with one atomic per wave and region
 // The four waves of a block run independently (no barrier) until the fresh tiles. Same arithmetic, same tie-break: the image is
 // bit-identical to the other schedules (tests/test_gpu_parity.py::test_traversal_schedules_agree).
-constexpr int kStreamStackLds = 6;
-constexpr uint32_t kStreamSteps = 6;                    // walk steps between two harvests
-constexpr uint32_t kStreamRefillMin = 12;               // idle lanes worth a refill
+#ifndef PT_STREAM_STEPS
+#define PT_STREAM_STEPS 6
+#define PT_STREAM_REFILL 12
+#define PT_STREAM_TRI 16
+#define PT_STREAM_ENTER 16
+#define PT_STREAM_NODE 24
+#endif
+#ifndef PT_STREAM_SPLIT
+#define PT_STREAM_SPLIT 1
+#endif
+constexpr int kStreamStackLds = 8;
+constexpr uint32_t kStreamSteps = PT_STREAM_STEPS;      // walk steps between two harvests
+constexpr uint32_t kStreamRefillMin = PT_STREAM_REFILL; // idle lanes worth a refill
+constexpr uint32_t kStreamTriMin = PT_STREAM_TRI;       // lanes waiting with a triangle before the triangle section runs ...
+constexpr uint32_t kStreamEnterMin = PT_STREAM_ENTER;   // ... with an instance to enter before the instance section runs ...
+constexpr uint32_t kStreamNodeMin = PT_STREAM_NODE;     // ... unless fewer lanes than this have a node to visit anyway
 constexpr uint32_t kStreamDone = 128;                   // done-list entries per wave
 constexpr uint32_t kStreamLdsStack = (uint32_t)kStreamStackLds * 256u * 8u;
 constexpr uint32_t kStreamLdsRays = 256u * 32u;
@@ -827,8 +840,162 @@ PT_DEV void wave_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counterB
     slotB = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & lt);
 }
 
+// The traversal half alone, same streaming walk: hits go to the queue's hit records (16 B per ray through HBM, nothing next to
+// the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
+#ifndef PT_EXTSTREAM_WAVES
+#define PT_EXTSTREAM_WAVES 5
+#endif
+template <bool STATS, bool WRITE_T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREAM_WAVES, PT_EXTSTREAM_WAVES))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
+                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues;
+    const uint32_t nT = count[sq];
+    const uint32_t seg = sq * segCap;
+    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
+    if (!nT) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    BlobReader<false> blob; blob.p = bv.base;
+    uint2 spill[kStackSize - kStreamStackLds];
+    GroupStack<kStreamStackLds> stack; stack.init((PT_LDS_AS void*)smem, spill);
+    PT_LDS_AS f4v* worldRay = (PT_LDS_AS f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;      // o.xyz tmin | d.xyz tmax of the lane's ray
+    constexpr uint32_t kMarker = 0xFFFFFFFFu;
+    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
+    uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, pendingInst = ~0u;
+    float tmin = 0.0f;
+    BoxRay br; br.o = V3(0, 0, 0); br.idir = V3(1, 1, 1); br.octinv4 = 0;
+    RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
+    Hit h; h.t = 0.0f; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
+    uint2 G = make_uint2(0u, 0u), T = make_uint2(0u, 0u);
+    bool exhausted = false;                                  // wave-uniform
+    const bool oneInstance = bv.instCount == 1u;
+    while (true) {
+        const unsigned long long busy = __ballot(qi != ~0u);
+        if (exhausted && !busy) break;
+        {
+            const unsigned long long idle = ~busy;
+            const uint32_t nIdle = (uint32_t)__popcll(idle);
+            if (!exhausted && (nIdle >= kStreamRefillMin || !busy)) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&cursor[sq], nIdle);
+                base = (uint32_t)__shfl((int)base, 0);
+                if (base + nIdle >= nT) exhausted = true;
+                if (qi == ~0u) {
+                    const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
+                    if (e < nT) {
+                        const float4 o = q.r0[seg + e], d = q.r1[seg + e];
+                        worldRay[0] = (f4v){ o.x, o.y, o.z, o.w }; worldRay[1] = (f4v){ d.x, d.y, d.z, d.w };
+                        qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16; pendingInst = ~0u;
+                        br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
+                        h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
+                        G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
+                        stack.sp = 0;
+                    }
+                }
+            }
+        }
+        bool finished = false;
+        #pragma unroll 1
+        for (uint32_t step = 0; step < kStreamSteps; step++) {
+            const bool live = qi != ~0u && !finished;
+            const bool top = curInst == ~0u;
+            const bool wantNode = live && G.y > 0x00FFFFFFu;
+            const bool leaf = live && T.y != 0u;
+            const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode));
+            const bool doTri = (uint32_t)__popcll(__ballot(leaf && !top)) >= kStreamTriMin || nNode < kStreamNodeMin;
+            const bool doEnter = (uint32_t)__popcll(__ballot(leaf && top)) >= kStreamEnterMin || nNode < kStreamNodeMin;
+            // what this lane does: 0 nothing, 1 node, 2 triangle, 3 instance look-up (order list), 4 instance entry
+            uint32_t act = 0, addr = 0, item = 0;
+            if (leaf && (top ? doEnter : doTri)) {
+                if (top && pendingInst != ~0u) { act = 4u; addr = bv.instOff16 + pendingInst * kInst16; }
+                else {
+                    item = T.x + (uint32_t)__builtin_ctz(T.y);
+                    if (top) { act = 3u; }
+                    else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
+                }
+            } else if (wantNode) {
+                if (T.y) { stack.push(T); T.y = 0u; }                    // postpone the leaf group
+                act = 1u;
+                const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
+                G.y &= ~(1u << bit);
+                if (G.y > 0x00FFFFFFu) stack.push(G);
+                const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
+                addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
+            }
+            // ---- all loads of the step
+            f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
+            uint32_t ordered = 0;
+            if (act == 3u) ordered = blob.ld32(bv.orderOff16 * 4u + item);
+            if (act == 1u || act == 2u || act == 4u) { L0 = blob.ld(addr); L1 = blob.ld(addr + 1); L2 = blob.ld(addr + 2); }
+            if (act == 1u || act == 4u) { L3 = blob.ld(addr + 3); L4 = blob.ld(addr + 4); }
+            if (act == 4u) L5 = blob.ld(addr + 5);
+            // ---- sections
+            if (act == 1u) {
+                if (STATS) st.nodes++;
+                const uint32_t hits = wide_node_hits(L0, L1, L2, L3, L4, br, tmin, h.t);
+                G = make_uint2(__float_as_uint(L1.x), (hits & 0xFF000000u) | (__float_as_uint(L0.w) >> 24));
+                T = make_uint2(__float_as_uint(L1.y), hits & 0x00FFFFFFu);
+            }
+            if (act == 2u) {
+                if (STATS) st.tris++;
+                float t, u, v;
+                if (tri_test(rs, br.o, V3(L0.x, L0.y, L0.z), V3(L1.x, L1.y, L1.z), V3(L2.x, L2.y, L2.z), t, u, v))
+                    commit_candidate(ac, __float_as_uint(L2.w), h, tmin, t, u, v, curInst, __float_as_uint(L0.w), __float_as_uint(L1.w), item);
+            }
+            if (act == 3u) pendingInst = ordered;
+            if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
+                T.y &= T.y - 1u;
+                const uint32_t ntri = __float_as_uint(L5.y);
+                if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
+                    const f4v wo = worldRay[0], wd = worldRay[1];
+                    const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
+                    const v3 rd = V3(L0.x * wd.x + L0.y * wd.y + L0.z * wd.z, L1.x * wd.x + L1.y * wd.y + L1.z * wd.z, L2.x * wd.x + L2.y * wd.y + L2.z * wd.z);
+                    rs = ray_setup(rd);
+                    br = box_ray(ro, rd);
+                    nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;
+                    triBase16 = bv.triOff16 + __float_as_uint(L4.w) * kTri16;
+                    stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
+                    const bool single = blas_single_leaf(ntri);
+                    G = root_node_group(single); T = root_tri_group(single, ntri);
+                    curInst = pendingInst;
+                }
+                pendingInst = ~0u;
+            }
+            // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
+            if (live && !T.y && G.y <= 0x00FFFFFFu) {
+                if (stack.sp > 0) {
+                    const uint2 e = stack.pop();
+                    if (e.x == kMarker && e.y == 0u) {                    // leave the BLAS: back to the world-space ray
+                        if (stack.overflow) { finished = true; stack.sp = 0; }
+                        else {
+                            T = stack.pop(); G = stack.pop();
+                            const f4v wo = worldRay[0], wd = worldRay[1];
+                            br = box_ray(V3(wo.x, wo.y, wo.z), V3(wd.x, wd.y, wd.z)); nodeBase16 = bv.nodeOff16; curInst = ~0u;
+                        }
+                    } else if (e.y > 0x00FFFFFFu) G = e;
+                    else T = e;                                           // a postponed leaf group of the current level
+                } else finished = true;
+            }
+        }
+        if (finished) {
+            const f4v wd = worldRay[1];
+            const bool hit = h.inst != ~0u && h.t < wd.w;
+            q.hit[seg + qi] = make_uint4(hit ? h.inst : ~0u, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
+            if (WRITE_T) q.r1[seg + qi].w = h.t;
+            qi = ~0u;
+        }
+    }
+    if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
+    if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
+}
+
+#ifndef PT_STREAM_WAVES
+#define PT_STREAM_WAVES 4
+#endif
 template <bool TEXTURED, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round_stream(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_STREAM_WAVES, PT_STREAM_WAVES))) void k_round_stream(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                BlobView bv, PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* cursorIn,
                                                uint32_t* countOut, DeviceCounters* counters)
 {
@@ -846,8 +1013,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         BlobReader<false> blob; blob.p = bv.base;
         AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
         uint2 spill[kStackSize - kStreamStackLds];
-        GroupStack<kStreamStackLds> stack; stack.init((uint2*)smem, spill);
-        f4v* worldRay = (f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;                 // o.xyz tmin | d.xyz tmax of the lane's ray
+        GroupStack<kStreamStackLds> stack; stack.init((PT_LDS_AS void*)smem, spill);
+        PT_LDS_AS f4v* worldRay = (PT_LDS_AS f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;      // o.xyz tmin | d.xyz tmax of the lane's ray
         unsigned char* mine = smem + kStreamLdsStack + kStreamLdsRays + wave * kStreamLdsWave;
         f4v* doneHit = (f4v*)mine;                                                       // t u v slot
         uint32_t* doneInst = (uint32_t*)(mine + kStreamDone * 16u);
@@ -856,7 +1023,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
 
         // lane state. qi: queue entry of the ray in flight (~0u: idle). curInst == ~0u: the walk is in the top level.
-        uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0;
+        uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, pendingInst = ~0u;
         float tmin = 0.0f;
         BoxRay br; br.o = V3(0, 0, 0); br.idir = V3(1, 1, 1); br.octinv4 = 0;
         RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
@@ -909,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         if (e < nT) {
                             const float4 o = qin.r0[seg + e], d = qin.r1[seg + e];
                             worldRay[0] = (f4v){ o.x, o.y, o.z, o.w }; worldRay[1] = (f4v){ d.x, d.y, d.z, d.w };
-                            qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16;
+                            qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16; pendingInst = ~0u;
                             br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                             h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
                             G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
@@ -918,57 +1085,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                 }
             }
-            // ---- walk
+            // ---- walk. One step = one memory round trip for the whole wave: every lane first decides what it will do (visit a node,
+            // test a triangle, look an instance up, enter it), ALL lanes issue their loads together, and only then the sections run.
+            // (With the loads inside the sections a step cost one dependent latency per section, and the four waves of a SIMD could
+            // not cover them: PMC r02_c, VALU 27 % busy, 55 % of wave cycles waiting.)
+            // Node visits are the common work and run every step; triangle tests and instance entries are leaf work that only a few
+            // lanes have at any time: a lane that has both postpones its leaf group on the stack and keeps visiting nodes until
+            // enough lanes wait with leaf work for the section to run with decent lane use (Ylitie et al. 2017, 4.3).
             bool finished = false;
             #pragma unroll 1
             for (uint32_t step = 0; step < kStreamSteps; step++) {
                 const bool live = qi != ~0u && !finished;
-                if (live && !T.y && G.y <= 0x00FFFFFFu) {                     // nothing at hand: pop, or the ray is done
+                const bool top = curInst == ~0u;
+                const bool wantNode = live && G.y > 0x00FFFFFFu;
+                const bool leaf = live && T.y != 0u;
+                const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode));
+                const bool doTri = (uint32_t)__popcll(__ballot(leaf && !top)) >= kStreamTriMin || nNode < kStreamNodeMin;
+                const bool doEnter = (uint32_t)__popcll(__ballot(leaf && top)) >= kStreamEnterMin || nNode < kStreamNodeMin;
+                // what this lane does: 0 nothing, 1 node, 2 triangle, 3 instance look-up (order list), 4 instance entry
+                uint32_t act = 0, addr = 0, item = 0;
+                if (leaf && (top ? doEnter : doTri)) {
+                    if (top && pendingInst != ~0u) { act = 4u; addr = bv.instOff16 + pendingInst * kInst16; }
+                    else {
+                        item = T.x + (uint32_t)__builtin_ctz(T.y);
+                        if (top) { act = 3u; }
+                        else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
+                    }
+                } else if (wantNode) {
+                    if (T.y) { stack.push(T); T.y = 0u; }                    // postpone the leaf group
+                    act = 1u;
+                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
+                    G.y &= ~(1u << bit);
+                    if (G.y > 0x00FFFFFFu) stack.push(G);
+                    const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
+                    addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
+                }
+                // ---- all loads of the step
+                f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
+                uint32_t ordered = 0;
+                if (act == 3u) ordered = blob.ld32(bv.orderOff16 * 4u + item);
+                if (act == 1u || act == 2u || act == 4u) { L0 = blob.ld(addr); L1 = blob.ld(addr + 1); L2 = blob.ld(addr + 2); }
+                if (act == 1u || act == 4u) { L3 = blob.ld(addr + 3); L4 = blob.ld(addr + 4); }
+                if (act == 4u) L5 = blob.ld(addr + 5);
+                // ---- sections
+                if (act == 1u) {
+                    if (STATS) st.nodes++;
+                    const uint32_t hits = wide_node_hits(L0, L1, L2, L3, L4, br, tmin, h.t);
+                    G = make_uint2(__float_as_uint(L1.x), (hits & 0xFF000000u) | (__float_as_uint(L0.w) >> 24));
+                    T = make_uint2(__float_as_uint(L1.y), hits & 0x00FFFFFFu);
+                }
+                if (act == 2u) {
+                    if (STATS) st.tris++;
+                    float t, u, v;
+                    if (tri_test(rs, br.o, V3(L0.x, L0.y, L0.z), V3(L1.x, L1.y, L1.z), V3(L2.x, L2.y, L2.z), t, u, v))
+                        commit_candidate(ac, __float_as_uint(L2.w), h, tmin, t, u, v, curInst, __float_as_uint(L0.w), __float_as_uint(L1.w), item);
+                }
+                if (act == 3u) pendingInst = ordered;
+                if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
+                    T.y &= T.y - 1u;
+                    const uint32_t ntri = __float_as_uint(L5.y);
+                    if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
+                        const f4v wo = worldRay[0], wd = worldRay[1];
+                        const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
+                        const v3 rd = V3(L0.x * wd.x + L0.y * wd.y + L0.z * wd.z, L1.x * wd.x + L1.y * wd.y + L1.z * wd.z, L2.x * wd.x + L2.y * wd.y + L2.z * wd.z);
+                        rs = ray_setup(rd);
+                        br = box_ray(ro, rd);
+                        nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;
+                        triBase16 = bv.triOff16 + __float_as_uint(L4.w) * kTri16;
+                        stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
+                        const bool single = blas_single_leaf(ntri);
+                        G = root_node_group(single); T = root_tri_group(single, ntri);
+                        curInst = pendingInst;
+                    }
+                    pendingInst = ~0u;
+                }
+                // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
+                if (live && !T.y && G.y <= 0x00FFFFFFu) {
                     if (stack.sp > 0) {
-                        G = stack.pop();
-                        if (G.x == kMarker && G.y == 0u) {                    // leave the BLAS: back to the world-space ray
-                            if (stack.overflow) { finished = true; stack.sp = 0; G = make_uint2(0u, 0u); }
+                        const uint2 e = stack.pop();
+                        if (e.x == kMarker && e.y == 0u) {                    // leave the BLAS: back to the world-space ray
+                            if (stack.overflow) { finished = true; stack.sp = 0; }
                             else {
                                 T = stack.pop(); G = stack.pop();
                                 const f4v wo = worldRay[0], wd = worldRay[1];
                                 br = box_ray(V3(wo.x, wo.y, wo.z), V3(wd.x, wd.y, wd.z)); nodeBase16 = bv.nodeOff16; curInst = ~0u;
                             }
-                        }
+                        } else if (e.y > 0x00FFFFFFu) G = e;
+                        else T = e;                                           // a postponed leaf group of the current level
                     } else finished = true;
-                }
-                if (live && !finished && !T.y && G.y > 0x00FFFFFFu)
-                    visit_node<STATS, false>(blob, nodeBase16, br, tmin, h.t, G, T, stack, &st);
-                if (live && !finished && T.y && curInst == ~0u) {             // a TLAS "triangle": enter the instance
-                    const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
-                    T.y &= T.y - 1u;
-                    const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
-                    const uint32_t ia = bv.instOff16 + x * kInst16;
-                    const f4v mk = blob.ld(ia + 5);
-                    const uint32_t ntri = __float_as_uint(mk.y);
-                    if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
-                        const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
-                        const f4v wo = worldRay[0], wd = worldRay[1];
-                        const v3 ro = V3(w0.x * wo.x + w0.y * wo.y + w0.z * wo.z + w0.w, w1.x * wo.x + w1.y * wo.y + w1.z * wo.z + w1.w, w2.x * wo.x + w2.y * wo.y + w2.z * wo.z + w2.w);
-                        const v3 rd = V3(w0.x * wd.x + w0.y * wd.y + w0.z * wd.z, w1.x * wd.x + w1.y * wd.y + w1.z * wd.z, w2.x * wd.x + w2.y * wd.y + w2.z * wd.z);
-                        rs = ray_setup(rd);
-                        br = box_ray(ro, rd);
-                        nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-                        triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
-                        stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
-                        const bool single = blas_single_leaf(ntri);
-                        G = root_node_group(single); T = root_tri_group(single, ntri);
-                        curInst = x;
-                    }
-                }
-                if (live && !finished && T.y && curInst != ~0u) {             // one triangle of the current BLAS
-                    const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
-                    T.y &= T.y - 1u;
-                    const uint32_t ta = triBase16 + i * kTri16;
-                    const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
-                    if (STATS) st.tris++;
-                    float t, u, v;
-                    if (tri_test(rs, br.o, V3(pa.x, pa.y, pa.z), V3(pb.x, pb.y, pb.z), V3(pc.x, pc.y, pc.z), t, u, v))
-                        commit_candidate(ac, __float_as_uint(pc.w), h, tmin, t, u, v, curInst, __float_as_uint(pa.w), __float_as_uint(pb.w), i);
                 }
             }
             // ---- harvest
@@ -1009,7 +1213,7 @@ __global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, Pa
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
     uint2 spill[kStackSize - kLdsStackDepth];
-    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    GroupStack<kLdsStackDepth> stack; stack.init((PT_LDS_AS void*)ldsStack, spill);
     BlobReader<false> blob; blob.p = bv.base;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t local = bq * 256u + threadIdx.x; local < n; local += nbq * 256u) {
@@ -1030,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_visibility(BlobView bv, AlphaContext ac
 {
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
     uint2 spill[kStackSize - kLdsStackDepth];
-    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    GroupStack<kLdsStackDepth> stack; stack.init((PT_LDS_AS void*)ldsStack, spill);
     BlobReader<false> blob; blob.p = bv.base;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
@@ -1047,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_debug_trace(BlobView bv, AlphaContext a
 {
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
     uint2 spill[kStackSize - kLdsStackDepth];
-    GroupStack<kLdsStackDepth> stack; stack.init(ldsStack, spill);
+    GroupStack<kLdsStackDepth> stack; stack.init((PT_LDS_AS void*)ldsStack, spill);
     BlobReader<false> blob; blob.p = bv.base;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     // lane 0 traces the ray and logs; the other lanes trace neighbours of it (rotated a little more per lane) without a log, so that
@@ -1211,6 +1415,24 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
         // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
         const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+        if (!lds && !(c.debugFlags & lockStep) && PT_STREAM_SPLIT) {
+            const bool wt = aux != nullptr;
+            for (uint32_t r = 0; r <= rounds; r++) {
+                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
+                timing_begin(c, c.evShade, c.nShade);
+                if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
+                else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
+                timing_end(c, c.evShade, c.nShade); c.nShade++;
+                if (r == rounds) break;
+                timing_begin(c, c.evExtend, c.nExtend);
+                #define PT_XS(S, W) k_extend_stream<S, W><<<grid, 256, kStreamLdsStack + kStreamLdsRays, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
+                if (stats) { if (wt) PT_XS(true, true); else PT_XS(true, false); } else { if (wt) PT_XS(false, true); else PT_XS(false, false); }
+                #undef PT_XS
+                timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
+            }
+            return hipGetLastError();
+        }
         if (!lds && !(c.debugFlags & lockStep)) {
             for (uint32_t r = 0; r <= rounds; r++) {
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];

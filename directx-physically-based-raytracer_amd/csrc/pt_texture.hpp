@@ -18,17 +18,24 @@ enum : uint32_t { kFmtRGBA8 = 0, kFmtRGBA8Srgb = 1, kFmtRGBA32F = 2 };
 
 struct f4 { float x, y, z, w; };
 
+// Heap pointers come out of a table in memory, so the compiler cannot tell which address space they point into and would emit
+// flat_* accesses -- which wait for every outstanding LDS and memory operation of the wave. They are device (global) memory by
+// the contract of pt_heap_set_*: say so.
+#define PT_GLOBAL_AS __attribute__((address_space(1)))
+template <typename T> PT_DEV const PT_GLOBAL_AS T* gptr(const void* p) { return (const PT_GLOBAL_AS T*)p; }
+
 PT_DEV f4 texel_fetch(const HeapEntry& t, const float* srgbLut, uint32_t face, uint32_t x, uint32_t y)
 {
     const uint32_t W = (uint32_t)(t.bytes & 0xFFFFFFFFu), H = (uint32_t)(t.bytes >> 32);
     const size_t idx = ((size_t)face * H + y) * W + x;
     f4 o;
     if (t.stride == kFmtRGBA32F) {
-        const float4 v = ((const float4*)t.ptr)[idx];
-        o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+        const PT_GLOBAL_AS float* v = gptr<float>(t.ptr) + 4 * idx;
+        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
         return o;
     }
-    const uchar4 p = ((const uchar4*)t.ptr)[idx];
+    const uint32_t pw = gptr<uint32_t>(t.ptr)[idx];
+    const uchar4 p = make_uchar4((uint8_t)(pw & 0xFFu), (uint8_t)((pw >> 8) & 0xFFu), (uint8_t)((pw >> 16) & 0xFFu), (uint8_t)(pw >> 24));
     if (t.stride == kFmtRGBA8Srgb) { o.x = srgbLut[p.x]; o.y = srgbLut[p.y]; o.z = srgbLut[p.z]; }
     else { o.x = unorm8_to_f32(p.x); o.y = unorm8_to_f32(p.y); o.z = unorm8_to_f32(p.z); }
     o.w = unorm8_to_f32(p.w);
@@ -90,7 +97,7 @@ enum : int { TEX_BaseColor = 0, TEX_EmissiveColor, TEX_Metallic, TEX_Roughness, 
 
 PT_DEV uint32_t load_index_tex(const void* ib, uint32_t stride, uint32_t i)
 {
-    return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
+    return stride == 2 ? (uint32_t)gptr<uint16_t>(ib)[i] : gptr<uint32_t>(ib)[i];
 }
 
 // GetTextureCoordinates, ShadingHelpers.hlsli:32-51
@@ -105,7 +112,7 @@ PT_DEV void get_texture_coordinates(const PtObjectData* od, const HeapEntry* hea
         float a[3][2];
         for (int k = 0; k < 3; k++) {
             const uint32_t idx = load_index_tex(ib.ptr, ib.stride, 3 * prim + k);
-            const uint16_t* h = (const uint16_t*)((const uint8_t*)vb.ptr + (size_t)od->VertexDesc.Stride * idx + off);
+            const PT_GLOBAL_AS uint16_t* h = gptr<uint16_t>((const uint8_t*)vb.ptr + (size_t)od->VertexDesc.Stride * idx + off);
             a[k][0] = f16_to_f32(h[0]); a[k][1] = f16_to_f32(h[1]);
         }
         for (int c = 0; c < 2; c++) tc.uv[i][c] = a[0][c] + bu * (a[1][c] - a[0][c]) + bv * (a[2][c] - a[0][c]);

@@ -89,13 +89,20 @@ __host__ __device__ inline bool blas_single_leaf(uint32_t triCount) { return tri
 PT_DEV uint2 root_node_group(bool singleLeaf) { return singleLeaf ? make_uint2(0u, 0u) : make_uint2(0u, 0x80000000u); }
 PT_DEV uint2 root_tri_group(bool singleLeaf, uint32_t count) { return singleLeaf ? make_uint2(0u, (1u << count) - 1u) : make_uint2(0u, 0u); }
 
+#define PT_LDS_AS __attribute__((address_space(3)))
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+
+// The first LDS_DEPTH entries of a lane live in LDS (entry d of thread t at lds[d * 256 + t]: ds_write_b64 / ds_read_b64,
+// conflict-free), deeper ones in a private array. The LDS part is addressed through an LDS pointer on purpose: through a generic
+// pointer every push and pop is a flat_* access, which makes the wave wait for ALL its outstanding memory operations (flat
+// accesses complete out of order: vmcnt(0) and lgkmcnt(0)) -- including the node fetch it was meant to overlap with.
 template <int LDS_DEPTH>
-struct GroupStack {                                        // entry d of thread t at lds[d * 256 + t]: ds_write_b64, conflict-free
-    uint2* lds; uint2* spill; int sp; uint32_t overflow;
-    PT_DEV void init(uint2* ldsBase, uint2* spillBase) { lds = ldsBase + threadIdx.x; spill = spillBase; sp = 0; overflow = 0; }
+struct GroupStack {
+    PT_LDS_AS u2v* lds; uint2* spill; int sp; uint32_t overflow;
+    PT_DEV void init(PT_LDS_AS void* ldsBase, uint2* spillBase) { lds = (PT_LDS_AS u2v*)ldsBase + threadIdx.x; spill = spillBase; sp = 0; overflow = 0; }
     PT_DEV void push(uint2 v)
     {
-        if (sp < LDS_DEPTH) lds[sp * 256] = v;
+        if (sp < LDS_DEPTH) lds[sp * 256] = (u2v){ v.x, v.y };
         else if (sp < kStackSize) spill[sp - LDS_DEPTH] = v;
         else { overflow++; return; }                       // counted in PtCounters.StackOverflows (the builders make this unreachable)
         sp++;
@@ -103,7 +110,8 @@ struct GroupStack {                                        // entry d of thread 
     PT_DEV uint2 pop()
     {
         sp--;
-        return sp < LDS_DEPTH ? lds[sp * 256] : spill[sp - LDS_DEPTH];
+        if (sp < LDS_DEPTH) { const u2v e = lds[sp * 256]; return make_uint2(e.x, e.y); }
+        return spill[sp - LDS_DEPTH];
     }
 };
 

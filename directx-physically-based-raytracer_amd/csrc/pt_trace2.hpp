@@ -19,7 +19,6 @@
 
 namespace pt {
 
-#define PT_LDS_AS __attribute__((address_space(3)))
 
 struct alignas(16) InstanceT {        // 144 B = 9 x 16
     float worldToObject[12];
@@ -155,7 +154,7 @@ constexpr uint32_t kPhasedWaveLds = 64u * 32u + kPhasedItems * 16u + kPhasedItem
 
 template <bool STATS, bool LDS, int STACK_DEPTH>
 PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                            uint2* ldsStack, uint32_t* ldsCand, unsigned char* ldsWave, TraceStats* stats)
+                            PT_LDS_AS void* ldsStack, uint32_t* ldsCand, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     if (bv.instCount == 0) return h;
@@ -247,7 +246,7 @@ constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 8u + 4u * kF
 
 template <bool STATS, bool LDS>
 PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                              uint2* ldsStack, unsigned char* ldsWave, TraceStats* stats)
+                              PT_LDS_AS void* ldsStack, unsigned char* ldsWave, TraceStats* stats)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     uint32_t quads = 0, meshes = 0;

@@ -60,7 +60,7 @@ def check_structure(ctx, expect_instances, expect_triangles):
     assert st["instances"] == expect_instances == acc.InstanceCount
     assert acc.TriangleCount == expect_triangles
     assert st["blas_depth"] == acc.MaxBottomLevelDepth and st["tlas_depth"] == acc.TopLevelDepth
-    assert st["tlas_depth"] + st["blas_depth"] + 4 <= 64          # kStackSize
+    assert 2 * (st["tlas_depth"] + st["blas_depth"]) + 4 <= 64    # kStackSize: node group + postponed leaf group per level, instance transition
     return st, acc
 
 
