@@ -182,7 +182,8 @@ __device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j)
 }
 
 // internal node i in [0, n-1): children + parent links. child < 0 means leaf ~(leaf index).
-__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children, int* __restrict__ parentInternal, int* __restrict__ parentLeaf)
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children, int* __restrict__ parentInternal, int* __restrict__ parentLeaf,
+                         uint2* __restrict__ range)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -206,16 +207,41 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
     int left = (lo == gamma) ? ~gamma : gamma;
     int right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     children[i] = make_int2(left, right);
+    range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);              // leaves [lo, hi] hang below node i: contiguous in Morton order
     if (left < 0) parentLeaf[~left] = i; else parentInternal[left] = i;
     if (right < 0) parentLeaf[~right] = i; else parentInternal[right] = i;
     if (i == 0) parentInternal[0] = -1;
 }
 
-// Boxes of the binary nodes: one thread per leaf climbs towards the root; the second arrival at a node owns it.
-// rootBounds: lo.xyz hi.xyz of the whole tree.
+// Boxes of the binary nodes and, with dp != nullptr, the cost tables of the optimal collapse: one thread per leaf climbs
+// towards the root; the second arrival at a node owns it. rootBounds: lo.xyz hi.xyz of the whole tree.
+//
+// Collapse cost model (Ylitie, Karras, Laine 2017, section 3.1). C(n, i) = cheapest SAH cost of the subtree of binary node n
+// represented as a forest of at most i roots, each a leaf (<= maxLeafItems items) or a wide node:
+//   C(n, 1) = min(C_leaf(n), C_internal(n)),  C_leaf(n) = A_n * P_n * c_item,  C_internal(n) = A_n * c_node + C_distribute(n, 8)
+//   C(n, i) = min(C_distribute(n, i), C(n, i - 1)),   C_distribute(n, j) = min over 0 < k < j of C(left, k) + C(right, j - k)
+// The decisions are kept (which k, leaf or node) and the collapse kernel follows them top-down.
+struct DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[2]; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
+static_assert(sizeof(DpNode) == 40, "layout");
+constexpr float kCostNode = 1.0f;
+#ifndef PT_COST_TRI
+#define PT_COST_TRI 0.3f
+#define PT_COST_INST 1.0f
+#endif
+constexpr float kCostTriangle = PT_COST_TRI;         // a triangle test against a node visit (measured instruction counts: ~80 against ~245)
+constexpr float kCostInstance = PT_COST_INST;        // entering an instance: look-up, ray transform, BLAS root
+
+__device__ __forceinline__ float half_area(float4 lo, float4 hi)
+{
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    const float a = dx * dy + dy * dz + dz * dx;
+    return a == a && dx >= 0.0f ? a : 0.0f;               // empty boxes (inverted, infinite) never attract the collapse
+}
+
 __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi,
                         const int2* __restrict__ children, const int* __restrict__ parentInternal, const int* __restrict__ parentLeaf,
-                        float4* nodeLo, float4* nodeHi, uint32_t* arrival, float* rootBounds)
+                        float4* nodeLo, float4* nodeHi, uint32_t* arrival, float* rootBounds,
+                        DpNode* dp, const uint2* __restrict__ range, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem)
 {
     int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaves) return;
@@ -236,6 +262,42 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
         const float4 lo = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
         const float4 hi = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
         nodeLo[cur] = lo; nodeHi[cur] = hi;
+        if (dp) {
+            float c[2][7];
+            for (int side = 0; side < 2; side++) {
+                const int r = side ? ch.y : ch.x;
+                if (r < 0) {
+                    const uint32_t first = (uint32_t)(~r) * leafSize, cnt = min(leafSize, nitems - first);
+                    const float v = half_area(side ? lo1 : lo0, side ? hi1 : hi0) * (float)cnt * costItem;
+                    for (int i = 0; i < 7; i++) c[side][i] = v;
+                } else {
+                    for (int i = 0; i < 7; i++) c[side][i] = dp[r].cost[i];
+                }
+            }
+            DpNode d;
+            float dist[9];
+            for (int j = 2; j <= 8; j++) {
+                float best = INFINITY; int bk = 1;
+                for (int k = 1; k < j; k++) {
+                    if (k > 7 || j - k > 7) continue;
+                    const float v = c[0][k - 1] + c[1][j - k - 1];
+                    if (v < best) { best = v; bk = k; }
+                }
+                dist[j] = best; d.split[j] = (uint8_t)bk;
+            }
+            const float A = half_area(lo, hi);
+            const uint2 rg = range[cur];
+            const uint32_t first = rg.x * leafSize, last = min((rg.y + 1u) * leafSize, nitems), P = last - first;
+            const float cLeaf = P <= maxLeafItems ? A * (float)P * costItem : INFINITY;
+            const float cInternal = A * kCostNode + dist[8];
+            d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0; d._pad[0] = d._pad[1] = 0;
+            d.cost[0] = fminf(cLeaf, cInternal);
+            for (int i = 2; i <= 7; i++) {
+                if (dist[i] < d.cost[i - 2]) d.cost[i - 1] = dist[i];
+                else { d.cost[i - 1] = d.cost[i - 2]; d.split[i] = 0; }
+            }
+            dp[cur] = d;
+        }
         if (cur == 0) {
             rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z; rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
         }
@@ -252,12 +314,6 @@ constexpr uint32_t kMaxWideLevels = 60;                  // a deeper tree cannot
 __device__ __forceinline__ void ref_box(int r, const float4* leafLo, const float4* leafHi, const float4* nodeLo, const float4* nodeHi, float4& lo, float4& hi)
 {
     if (r < 0) { lo = leafLo[~r]; hi = leafHi[~r]; } else { lo = nodeLo[r]; hi = nodeHi[r]; }
-}
-__device__ __forceinline__ float half_area(float4 lo, float4 hi)
-{
-    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-    const float a = dx * dy + dy * dz + dz * dx;
-    return a == a && dx >= 0.0f ? a : 0.0f;               // empty boxes (inverted, infinite) never attract the collapse
 }
 
 // Origin, per-axis power-of-two scale and the 8-bit child boxes of a node (paper, section 3.3): e = ceil(log2(extent / 255)),
@@ -304,6 +360,7 @@ __device__ void quantise_node(WideNode& n, float4 nlo, float4 nhi, const float4*
 }
 
 struct CollapseArgs {
+    const DpNode* dp; const uint2* range;
     const int2* children; const float4* nodeLo; const float4* nodeHi; const float4* leafLo; const float4* leafHi;
     uint32_t nleaves, nitems, leafSize;
     WideNode* nodes; uint32_t nodeCapacity;
@@ -340,25 +397,27 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
         const uint32_t begin = sBegin, end = sEnd;
         if (begin >= end) break;
         for (uint32_t w = begin + tid; w < end; w += blockDim.x) {
-            int refs[8]; float4 lo[8], hi[8];
+            int refs[8]; float4 lo[8], hi[8]; bool leafChild[8];
             const int root = A.binaryRootOf[w];
-            int n = 2;
-            { const int2 c = A.children[root]; refs[0] = c.x; refs[1] = c.y; }
-            ref_box(refs[0], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[0], hi[0]);
-            ref_box(refs[1], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[1], hi[1]);
-            while (n < 8) {                                              // open the internal child with the largest surface area
-                int best = -1; float bestA = -1.0f;
-                for (int k = 0; k < n; k++) {
-                    if (refs[k] < 0) continue;
-                    const float a = half_area(lo[k], hi[k]);
-                    if (a > bestA) { bestA = a; best = k; }
+            int n = 0;
+            {   // the children the cost tables chose for this node: distribute 8 roots over the two subtrees, recursively
+                int sref[10]; int sbud[10]; int sp = 0;
+                const int2 c = A.children[root];
+                const int k8 = A.dp[root].split[8];
+                sref[sp] = c.y; sbud[sp++] = 8 - k8;
+                sref[sp] = c.x; sbud[sp++] = k8;
+                while (sp > 0) {
+                    const int m = sref[--sp], budget = sbud[sp];
+                    if (m < 0 || budget == 1) {
+                        if (n < 8) { refs[n] = m; leafChild[n] = m < 0 || A.dp[m].isLeaf; n++; } else sError = 1;
+                        continue;
+                    }
+                    const int k = A.dp[m].split[budget];
+                    if (k == 0) { sref[sp] = m; sbud[sp++] = budget - 1; }
+                    else { const int2 cm = A.children[m]; sref[sp] = cm.y; sbud[sp++] = budget - k; sref[sp] = cm.x; sbud[sp++] = k; }
                 }
-                if (best < 0) break;
-                const int2 c = A.children[refs[best]];
-                refs[best] = c.x; ref_box(c.x, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[best], hi[best]);
-                refs[n] = c.y; ref_box(c.y, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[n], hi[n]);
-                n++;
             }
+            for (int k = 0; k < n; k++) ref_box(refs[k], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[k], hi[k]);
             // slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2,
             // greedy instead of the auction: repeatedly the cheapest unassigned (child, slot) pair)
             float4 nlo, nhi;
@@ -382,13 +441,17 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
                 }
                 slotOf[bc] = bs; childAt[bs] = bc;
             }
-            // children and triangles of this node, in slot order
-            uint32_t nInternal = 0, nItems = 0, imask = 0;
+            // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at
+            // most kMaxLeafTris items (its leaves are consecutive in Morton order, so its items are one range)
+            uint32_t nInternal = 0, nItems = 0, imask = 0, firstItem[8], cntItem[8];
             for (int s = 0; s < 8; s++) {
                 const int c = childAt[s];
                 if (c < 0) continue;
-                if (refs[c] >= 0) { nInternal++; imask |= 1u << s; }
-                else { const uint32_t first = (uint32_t)(~refs[c]) * A.leafSize; nItems += min(A.leafSize, A.nitems - first); }
+                if (!leafChild[c]) { nInternal++; imask |= 1u << s; continue; }
+                uint32_t l0, l1;
+                if (refs[c] < 0) l0 = l1 = (uint32_t)(~refs[c]); else { const uint2 rg = A.range[refs[c]]; l0 = rg.x; l1 = rg.y; }
+                firstItem[c] = l0 * A.leafSize; cntItem[c] = min((l1 + 1u) * A.leafSize, A.nitems) - firstItem[c];
+                nItems += cntItem[c];
             }
             const uint32_t childBase = nInternal ? atomicAdd(&sNodes, nInternal) : 0u;
             const uint32_t itemBase = nItems ? atomicAdd(&sItems, nItems) : 0u;
@@ -399,21 +462,23 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
             for (int s = 0; s < 8; s++) {
                 const int c = childAt[s];
                 meta[s] = 0; srefs[s] = kEmptyRef; slo[s] = make_float4(0, 0, 0, 0); shi[s] = slo[s];
-                if (c < 0) continue;
-                srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
-                if (refs[c] >= 0) {
-                    if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else sError = 1;
-                    ci++;
-                    meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
-                } else {
-                    const uint32_t leaf = (uint32_t)(~refs[c]), first = leaf * A.leafSize, cnt = min(A.leafSize, A.nitems - first);
-                    A.leafDst[leaf] = itemBase + ti;
-                    meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
-                    ti += cnt;
+                if (c >= 0) {
+                    srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
+                    if (!leafChild[c]) {
+                        if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else sError = 1;
+                        ci++;
+                        meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+                    } else {
+                        const uint32_t cnt = cntItem[c];
+                        if (cnt > kMaxLeafTris || ti + cnt > 24u) sError = 1;
+                        for (uint32_t l = firstItem[c] / A.leafSize; l * A.leafSize < firstItem[c] + cnt; l++)
+                            A.leafDst[l] = itemBase + ti + (l * A.leafSize - firstItem[c]);
+                        meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
+                        ti += cnt;
+                    }
                 }
                 A.slotRefs[(size_t)w * 8 + s] = srefs[s];
             }
-            for (int s = 0; s < 8; s++) if (childAt[s] < 0) A.slotRefs[(size_t)w * 8 + s] = kEmptyRef;
             node.meta[0] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
             node.meta[1] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
             quantise_node(node, nlo, nhi, slo, shi, srefs);
@@ -474,7 +539,7 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 void TreeBuffers::release()
 {
     void* ptrs[] = { boxLo, boxHi, bounds, keys, keysSorted, index, indexSorted, sortTemp, leafKeys, leafLo, leafHi, children, parentInternal,
-                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header };
+                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header, dp, range };
     for (void* p : ptrs) if (p) hipFree(p);
     *this = TreeBuffers();
 }
@@ -513,6 +578,8 @@ static hipError_t ensure_tree_buffers(TreeBuffers& b, uint32_t nitems, uint32_t 
     BVH_CHECK(hipMalloc((void**)&b.leafDst, sizeof(uint32_t) * nl));
     if (withPrimSlots) BVH_CHECK(hipMalloc((void**)&b.slotOfPrim, sizeof(uint32_t) * ni));
     BVH_CHECK(hipMalloc((void**)&b.header, sizeof(WideHeader)));
+    BVH_CHECK(hipMalloc(&b.dp, sizeof(DpNode) * nint));
+    BVH_CHECK(hipMalloc((void**)&b.range, sizeof(uint2) * nint));
     b.itemCapacity = (uint32_t)ni; b.leafCapacity = (uint32_t)nl;
     return hipSuccess;
 fail:
@@ -521,7 +588,7 @@ fail:
 }
 
 // items in b.boxLo/boxHi/bounds -> sorted -> binary tree -> wide nodes in `nodes` (capacity: wide_node_capacity(nleaves)); no sync
-static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, WideNode* nodes, float* rootBounds, hipStream_t stream)
+static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem, WideNode* nodes, float* rootBounds, hipStream_t stream)
 {
     hipError_t err = hipSuccess;
     const uint32_t nleaves = cdiv(nitems, leafSize);
@@ -530,14 +597,16 @@ static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leaf
         size_t tmp = b.sortTempBytes;
         BVH_CHECK(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.index, b.indexSorted, nitems, 0, 63, stream));
         k_leaves<<<cdiv(nleaves, 256), 256, 0, stream>>>(b.keysSorted, b.indexSorted, b.boxLo, b.boxHi, nitems, nleaves, leafSize, b.leafKeys, b.leafLo, b.leafHi);
-        if (nleaves > 1) k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(b.leafKeys, (int)nleaves, b.children, b.parentInternal, b.parentLeaf);
-        k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, b.leafLo, b.leafHi, b.children, b.parentInternal, b.parentLeaf, b.nodeLo, b.nodeHi, b.arrival, rootBounds);
+        if (nleaves > 1) k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(b.leafKeys, (int)nleaves, b.children, b.parentInternal, b.parentLeaf, b.range);
+        k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, b.leafLo, b.leafHi, b.children, b.parentInternal, b.parentLeaf, b.nodeLo, b.nodeHi, b.arrival, rootBounds,
+                                                     (DpNode*)b.dp, b.range, nitems, leafSize, maxLeafItems, costItem);
     } else {
         const float e[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
         BVH_CHECK(hipMemcpyAsync(rootBounds, e, sizeof e, hipMemcpyHostToDevice, stream));
     }
     {
         CollapseArgs A;
+        A.dp = (const DpNode*)b.dp; A.range = b.range;
         A.children = b.children; A.nodeLo = b.nodeLo; A.nodeHi = b.nodeHi; A.leafLo = b.leafLo; A.leafHi = b.leafHi;
         A.nleaves = nleaves; A.nitems = nitems; A.leafSize = leafSize; A.nodes = nodes; A.nodeCapacity = wide_node_capacity(nleaves);
         A.binaryRootOf = b.binaryRootOf; A.slotRefs = b.slotRefs; A.leafDst = b.leafDst; A.header = b.header;
@@ -576,7 +645,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
         }
         BVH_CHECK(hipGetLastError());
     }
-    BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, out.nodes, out.rootBounds, stream));
+    BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, kMaxLeafTris, kCostTriangle, out.nodes, out.rootBounds, stream));
     if (ntris) k_scatter_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, out.tree.indexSorted, out.tree.leafDst, ntris, leafSize, out.tris, out.tree.slotOfPrim);
     BVH_CHECK(hipMemcpyAsync(&hdr, out.tree.header, sizeof hdr, hipMemcpyDeviceToHost, stream));
     BVH_CHECK(hipStreamSynchronize(stream));     // build is a load-time operation (reference: CommandList::End after the BLAS build, Scene.ixx:184-188)
@@ -610,7 +679,7 @@ hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
     k_leaves<<<cdiv(b.leafCount, 256), 256, 0, stream>>>(nullptr, b.tree.indexSorted, b.tree.boxLo, b.tree.boxHi, b.triCount, b.leafCount, leafSize,
                                                          nullptr, b.tree.leafLo, b.tree.leafHi);
     k_refit<<<cdiv(b.leafCount, 256), 256, 0, stream>>>((int)b.leafCount, b.tree.leafLo, b.tree.leafHi, b.tree.children, b.tree.parentInternal,
-                                                        b.tree.parentLeaf, b.tree.nodeLo, b.tree.nodeHi, b.tree.arrival, b.rootBounds);
+                                                        b.tree.parentLeaf, b.tree.nodeLo, b.tree.nodeHi, b.tree.arrival, b.rootBounds, nullptr, nullptr, b.triCount, leafSize, 0, 0.0f);
     if (b.leafCount > 1)
         k_requantise<<<cdiv(b.nodeCount, 256), 256, 0, stream>>>(b.nodeCount, b.nodes, b.tree.binaryRootOf, b.tree.slotRefs, b.tree.leafLo, b.tree.leafHi,
                                                                  b.tree.nodeLo, b.tree.nodeHi);
@@ -647,7 +716,7 @@ hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* cons
         k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
         k_instance_boxes<<<cdiv(n, 256), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
-    BVH_CHECK(build_wide_tree(out.tree, n, 1, out.nodes, out.rootBounds, stream));
+    BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, out.nodes, out.rootBounds, stream));
     if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
     BVH_CHECK(hipGetLastError());
 fail:

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                     else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
                 }
             } else if (wantNode) {
-                if (T.y) { stack.push(T); T.y = 0u; }                    // postpone the leaf group
+                if (T.y) { stack.push(T); T.y = 0u; pendingInst = ~0u; }  // postpone the leaf group (a looked-up instance belongs to it: look it up again later)
                 act = 1u;
                 const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
                 G.y &= ~(1u << bit);
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_STREAM_W
                         else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
                     }
                 } else if (wantNode) {
-                    if (T.y) { stack.push(T); T.y = 0u; }                    // postpone the leaf group
+                    if (T.y) { stack.push(T); T.y = 0u; pendingInst = ~0u; }  // postpone the leaf group (a looked-up instance belongs to it: look it up again later)
                     act = 1u;
                     const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
                     G.y &= ~(1u << bit);

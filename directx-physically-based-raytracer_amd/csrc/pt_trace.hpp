@@ -144,7 +144,9 @@ PT_DEV float ubyte_f(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xFFu)
 // Slab test of a ray against the eight quantised child boxes of a node. Returns the paper's hit mask: bit 24 + (s ^ octinv)
 // for a hit internal child in slot s, bits [first, first + count) of the low 24 for the triangles of a hit leaf slot.
 // Conservative by construction: boxes are padded before quantisation and rounded outward by it, NaN slabs are ignored
-// (v_min/v_max drop NaN operands) and tfar is widened by 8 ulp, which covers the roundings of the decode below.
+// (v_min/v_max drop NaN operands), and every slab plane t = q * a + b is moved outward by a bound on its own rounding error:
+// a and b are products with the reciprocal direction of terms as large as the NODE (not the child), so the error of t scales
+// with |b| + 255 |a|, whatever the size of the child box -- folded into b, it costs nothing per child.
 PT_DEV uint32_t wide_node_hits(f4v n0, f4v n1, f4v n2, f4v n3, f4v n4, const BoxRay& r, float tmin, float tmax)
 {
     const uint32_t em = __float_as_uint(n0.w);
@@ -152,6 +154,10 @@ PT_DEV uint32_t wide_node_hits(f4v n0, f4v n1, f4v n2, f4v n3, f4v n4, const Box
     const float ay = __uint_as_float(((em >> 8) & 0xFFu) << 23) * r.idir.y;
     const float az = __uint_as_float(((em >> 16) & 0xFFu) << 23) * r.idir.z;
     const float bx = (n0.x - r.o.x) * r.idir.x, by = (n0.y - r.o.y) * r.idir.y, bz = (n0.z - r.o.z) * r.idir.z;
+    constexpr float kUlps = 4.76837158e-7f;                                      // 2^-21: four ulps of the largest term
+    const float ex = __builtin_fmaf(fabsf(ax), 255.0f, fabsf(bx)) * kUlps, ey = __builtin_fmaf(fabsf(ay), 255.0f, fabsf(by)) * kUlps,
+                ez = __builtin_fmaf(fabsf(az), 255.0f, fabsf(bz)) * kUlps;
+    const float bnx = bx - ex, bfx = bx + ex, bny = by - ey, bfy = by + ey, bnz = bz - ez, bfz = bz + ez;
     const bool nx = r.idir.x < 0.0f, ny = r.idir.y < 0.0f, nz = r.idir.z < 0.0f;
     uint32_t hits = 0;
     #pragma unroll
@@ -168,13 +174,13 @@ PT_DEV uint32_t wide_node_hits(f4v n0, f4v n1, f4v n2, f4v n3, f4v n4, const Box
         const uint32_t nearz = nz ? hiz : loz, farz = nz ? loz : hiz;
         #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float tnx = __builtin_fmaf(ubyte_f(nearx, j), ax, bx), tfx = __builtin_fmaf(ubyte_f(farx, j), ax, bx);
-            const float tny = __builtin_fmaf(ubyte_f(neary, j), ay, by), tfy = __builtin_fmaf(ubyte_f(fary, j), ay, by);
-            const float tnz = __builtin_fmaf(ubyte_f(nearz, j), az, bz), tfz = __builtin_fmaf(ubyte_f(farz, j), az, bz);
+            const float tnx = __builtin_fmaf(ubyte_f(nearx, j), ax, bnx), tfx = __builtin_fmaf(ubyte_f(farx, j), ax, bfx);
+            const float tny = __builtin_fmaf(ubyte_f(neary, j), ay, bny), tfy = __builtin_fmaf(ubyte_f(fary, j), ay, bfy);
+            const float tnz = __builtin_fmaf(ubyte_f(nearz, j), az, bnz), tfz = __builtin_fmaf(ubyte_f(farz, j), az, bfz);
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
             const uint32_t bits = (childBits4 >> (8 * j)) & 0xFFu, idx = (bitIndex4 >> (8 * j)) & 0xFFu;
-            if (tn <= tf * 1.000001f) hits |= bits << idx;
+            if (tn <= tf) hits |= bits << idx;
         }
     }
     return hits;
