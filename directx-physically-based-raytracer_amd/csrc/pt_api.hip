@@ -628,6 +628,7 @@ int pt_get_counters(PtContext* ctx, PtCounters* out)
     out->WavefrontIterations = c.lastIterations;
     out->BvhMismatches = d.mismatchCount;
     out->StackOverflows = d.stackOverflows;
+    out->MaxNodesPerRay = d.maxNodesPerRay;
     return PT_OK;
 }
 

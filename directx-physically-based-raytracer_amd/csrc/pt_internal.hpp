@@ -89,6 +89,7 @@ struct DeviceCounters {
     unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
     unsigned int mismatchCount, stackOverflows;   // PT_DEBUG_BRUTE_FORCE: rays whose BVH result differs from brute force | refused stack pushes (must be 0)
     float mismatchRay[16];                   // first such ray: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t -
+    unsigned int maxNodesPerRay, _pad2;      // PT_DEBUG_TRAVERSAL_STATS, streaming traversal: the longest walk
 };
 
 struct Context {

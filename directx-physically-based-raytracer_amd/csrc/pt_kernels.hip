@@ -792,58 +792,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming round for scenes whose blob lives in HBM / L2 (C3: one 250 k-triangle BLAS, C5: 10 k instances).
+// Streaming traversal for scenes whose blob lives in HBM / L2 (C3: one 250 k-triangle BLAS, C5: 10 k instances).
 // The lock-step forms above trace one tile of rays per wave and wait for the slowest lane: on incoherent bounce rays in a big
-// BVH (8..60 node visits per ray) a wave spent 8 of 9 issue slots on idle lanes (PMC, profiles/r02_b_c3: 540 VALU
+// BVH (8..150 node visits per ray) a wave spent 8 of 9 issue slots on idle lanes (PMC, profiles/r02_b_c3: 540 VALU
 // wave-instructions per ray against ~66 at full lanes). Here a wave is a set of 64 persistent traversal lanes:
 //   refill   idle lanes take the next rays of the sub-queue (one atomic on the sub-queue's cursor per refill, consecutive
 //            entries for consecutive idle lanes: coalesced reads) -- a lane that finishes early does not wait for its neighbours
 //   walk     kStreamSteps steps of the one-ray two-level walk (trace_single's state machine, one stack per lane in LDS)
-//   harvest  finished lanes append (queue entry, hit) to the wave's done list in LDS
-//   shade    whenever 64 hits are waiting the whole wave shades them, full lanes, with the same shade_traced / scatter
-//            as every other form, and emits survivors with one atomic per wave and region
-// The four waves of a block run independently (no barrier) until the fresh tiles. Same arithmetic, same tie-break: the image is
-// bit-identical to the other schedules (tests/test_gpu_parity.py::test_traversal_schedules_agree).
+//   harvest  finished lanes write their hit record; the shading half (k_shade) runs as its own launch, full lanes
+// Same arithmetic, same tie-break: the image is bit-identical to the other schedules
+// (tests/test_gpu_parity.py::test_streaming_and_lockstep_schedules_agree).
 #ifndef PT_STREAM_STEPS
 #define PT_STREAM_STEPS 6
 #define PT_STREAM_REFILL 12
-#define PT_STREAM_TRI 16
-#define PT_STREAM_ENTER 16
-#define PT_STREAM_NODE 24
-#endif
-#ifndef PT_STREAM_SPLIT
-#define PT_STREAM_SPLIT 1
+#define PT_STREAM_MINLANES 8
+#define PT_STREAM_SHARE 1
 #endif
 constexpr int kStreamStackLds = 8;
 constexpr uint32_t kStreamSteps = PT_STREAM_STEPS;      // walk steps between two harvests
 constexpr uint32_t kStreamRefillMin = PT_STREAM_REFILL; // idle lanes worth a refill
-constexpr uint32_t kStreamTriMin = PT_STREAM_TRI;       // lanes waiting with a triangle before the triangle section runs ...
-constexpr uint32_t kStreamEnterMin = PT_STREAM_ENTER;   // ... with an instance to enter before the instance section runs ...
-constexpr uint32_t kStreamNodeMin = PT_STREAM_NODE;     // ... unless fewer lanes than this have a node to visit anyway
-constexpr uint32_t kStreamDone = 128;                   // done-list entries per wave
+constexpr uint32_t kStreamMinLanes = PT_STREAM_MINLANES;   // a section (node visit / triangle test / instance entry) runs in a step when at least this many lanes ...
+constexpr uint32_t kStreamShareShift = PT_STREAM_SHARE;    // ... and at least (lanes of the busiest section >> this) wait for it; the busiest always runs
 constexpr uint32_t kStreamLdsStack = (uint32_t)kStreamStackLds * 256u * 8u;
-constexpr uint32_t kStreamLdsRays = 256u * 32u;
-constexpr uint32_t kStreamLdsWave = kStreamDone * 16u + kStreamDone * 4u + kStreamDone * 4u;      // hit t u v slot | instance | queue entry
-constexpr uint32_t kStreamLds = kStreamLdsStack + kStreamLdsRays + 4u * kStreamLdsWave;
-
-// wave-level twin of block_reserve2: two compactions, two returning atomics issued by two different lanes
-PT_DEV void wave_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t& slotA, uint32_t& slotB)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long ma = __ballot(a), mb = __ballot(b);
-    const uint32_t na = (uint32_t)__popcll(ma), nb = (uint32_t)__popcll(mb);
-    uint32_t base = 0;
-    if (lane == 0 && na) base = atomicAdd(counterA, na);
-    if (lane == 1 && nb) base = atomicAdd(counterB, nb);
-    slotA = (uint32_t)__shfl((int)base, 0) + (uint32_t)__popcll(ma & lt);
-    slotB = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & lt);
-}
 
 // The traversal half alone, same streaming walk: hits go to the queue's hit records (16 B per ray through HBM, nothing next to
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
 #ifndef PT_EXTSTREAM_WAVES
-#define PT_EXTSTREAM_WAVES 5
+#define PT_EXTSTREAM_WAVES 4
 #endif
 template <bool STATS, bool WRITE_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREAM_WAVES, PT_EXTSTREAM_WAVES))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
@@ -860,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     BlobReader<false> blob; blob.p = bv.base;
     uint2 spill[kStackSize - kStreamStackLds];
     GroupStack<kStreamStackLds> stack; stack.init((PT_LDS_AS void*)smem, spill);
-    PT_LDS_AS f4v* worldRay = (PT_LDS_AS f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;      // o.xyz tmin | d.xyz tmax of the lane's ray
+    v3 wo = V3(0, 0, 0), wd = V3(0, 0, 1); float wtmax = 0.0f;      // the lane's ray in world space
     constexpr uint32_t kMarker = 0xFFFFFFFFu;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
     uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, pendingInst = ~0u;
@@ -871,6 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     uint2 G = make_uint2(0u, 0u), T = make_uint2(0u, 0u);
     bool exhausted = false;                                  // wave-uniform
     const bool oneInstance = bv.instCount == 1u;
+    uint32_t rayNodes = 0;
     while (true) {
         const unsigned long long busy = __ballot(qi != ~0u);
         if (exhausted && !busy) break;
@@ -886,12 +862,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                     const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
                     if (e < nT) {
                         const float4 o = q.r0[seg + e], d = q.r1[seg + e];
-                        worldRay[0] = (f4v){ o.x, o.y, o.z, o.w }; worldRay[1] = (f4v){ d.x, d.y, d.z, d.w };
+                        wo = V3(o.x, o.y, o.z); wd = V3(d.x, d.y, d.z); wtmax = d.w;
                         qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16; pendingInst = ~0u;
                         br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                         h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
                         G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
                         stack.sp = 0;
+                        if (STATS) rayNodes = st.nodes;
                     }
                 }
             }
@@ -903,9 +880,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             const bool top = curInst == ~0u;
             const bool wantNode = live && G.y > 0x00FFFFFFu;
             const bool leaf = live && T.y != 0u;
-            const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode));
-            const bool doTri = (uint32_t)__popcll(__ballot(leaf && !top)) >= kStreamTriMin || nNode < kStreamNodeMin;
-            const bool doEnter = (uint32_t)__popcll(__ballot(leaf && top)) >= kStreamEnterMin || nNode < kStreamNodeMin;
+            // which sections run this step: the one most lanes wait for, and any other with enough lanes of its own
+            const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode)), nTri = (uint32_t)__popcll(__ballot(leaf && !top)),
+                           nEnter = (uint32_t)__popcll(__ballot(leaf && top));
+            const uint32_t most = max(nNode, max(nTri, nEnter));
+            const uint32_t lim = max(kStreamMinLanes, most >> kStreamShareShift);
+            const bool doNode = nNode >= lim || nNode == most, doTri = nTri >= lim || nTri == most, doEnter = nEnter >= lim || nEnter == most;
             // what this lane does: 0 nothing, 1 node, 2 triangle, 3 instance look-up (order list), 4 instance entry
             uint32_t act = 0, addr = 0, item = 0;
             if (leaf && (top ? doEnter : doTri)) {
@@ -915,7 +895,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                     if (top) { act = 3u; }
                     else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
                 }
-            } else if (wantNode) {
+            } else if (wantNode && doNode) {
                 if (T.y) { stack.push(T); T.y = 0u; pendingInst = ~0u; }  // postpone the leaf group (a looked-up instance belongs to it: look it up again later)
                 act = 1u;
                 const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
@@ -924,7 +904,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
                 addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
             }
-            // ---- all loads of the step
+            // ---- all loads of the step (a wave-cooperative gather through LDS -- neighbouring lanes fetching neighbouring 16-byte
+            // units of one record -- was tried here and lost 30 %: the walk is bound by VALU issue, not by the vector cache)
             f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
             uint32_t ordered = 0;
             if (act == 3u) ordered = blob.ld32(bv.orderOff16 * 4u + item);
@@ -949,7 +930,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 T.y &= T.y - 1u;
                 const uint32_t ntri = __float_as_uint(L5.y);
                 if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
-                    const f4v wo = worldRay[0], wd = worldRay[1];
                     const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
                     const v3 rd = V3(L0.x * wd.x + L0.y * wd.y + L0.z * wd.z, L1.x * wd.x + L1.y * wd.y + L1.z * wd.z, L2.x * wd.x + L2.y * wd.y + L2.z * wd.z);
                     rs = ray_setup(rd);
@@ -971,8 +951,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                         if (stack.overflow) { finished = true; stack.sp = 0; }
                         else {
                             T = stack.pop(); G = stack.pop();
-                            const f4v wo = worldRay[0], wd = worldRay[1];
-                            br = box_ray(V3(wo.x, wo.y, wo.z), V3(wd.x, wd.y, wd.z)); nodeBase16 = bv.nodeOff16; curInst = ~0u;
+                                    br = box_ray(wo, wd); nodeBase16 = bv.nodeOff16; curInst = ~0u;
                         }
                     } else if (e.y > 0x00FFFFFFu) G = e;
                     else T = e;                                           // a postponed leaf group of the current level
@@ -980,8 +959,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             }
         }
         if (finished) {
-            const f4v wd = worldRay[1];
-            const bool hit = h.inst != ~0u && h.t < wd.w;
+            const bool hit = h.inst != ~0u && h.t < wtmax;
+            if (STATS) atomicMax(&counters->maxNodesPerRay, st.nodes - rayNodes);
             q.hit[seg + qi] = make_uint4(hit ? h.inst : ~0u, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
             if (WRITE_T) q.r1[seg + qi].w = h.t;
             qi = ~0u;
@@ -989,220 +968,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
     if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
-}
-
-#ifndef PT_STREAM_WAVES
-#define PT_STREAM_WAVES 4
-#endif
-template <bool TEXTURED, bool STATS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_STREAM_WAVES, PT_STREAM_WAVES))) void k_round_stream(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
-                                               BlobView bv, PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* cursorIn,
-                                               uint32_t* countOut, DeviceCounters* counters)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t lds[16];
-    const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
-    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
-    const uint32_t seg = sq * segCap;
-    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-
-    if (nT) {
-        BlobReader<false> blob; blob.p = bv.base;
-        AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
-        uint2 spill[kStackSize - kStreamStackLds];
-        GroupStack<kStreamStackLds> stack; stack.init((PT_LDS_AS void*)smem, spill);
-        PT_LDS_AS f4v* worldRay = (PT_LDS_AS f4v*)(smem + kStreamLdsStack) + 2u * threadIdx.x;      // o.xyz tmin | d.xyz tmax of the lane's ray
-        unsigned char* mine = smem + kStreamLdsStack + kStreamLdsRays + wave * kStreamLdsWave;
-        f4v* doneHit = (f4v*)mine;                                                       // t u v slot
-        uint32_t* doneInst = (uint32_t*)(mine + kStreamDone * 16u);
-        uint32_t* doneEntry = (uint32_t*)(mine + kStreamDone * 20u);
-        constexpr uint32_t kMarker = 0xFFFFFFFFu;
-        TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
-
-        // lane state. qi: queue entry of the ray in flight (~0u: idle). curInst == ~0u: the walk is in the top level.
-        uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, pendingInst = ~0u;
-        float tmin = 0.0f;
-        BoxRay br; br.o = V3(0, 0, 0); br.idir = V3(1, 1, 1); br.octinv4 = 0;
-        RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
-        Hit h; h.t = 0.0f; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
-        uint2 G = make_uint2(0u, 0u), T = make_uint2(0u, 0u);
-        uint32_t nDone = 0;                                      // wave-uniform
-        bool exhausted = false;                                  // wave-uniform: the sub-queue has no ray left to hand out
-        const bool oneInstance = bv.instCount == 1u;
-
-        while (true) {
-            // ---- shade: 64 waiting hits (or the rest, once nothing is in flight any more)
-            const unsigned long long busy = __ballot(qi != ~0u);
-            if (nDone >= 64u || (exhausted && !busy && nDone)) {
-                const uint32_t count = nDone < 64u ? nDone : 64u, first = nDone - count;
-                bool toTraced = false, toFresh = false;
-                PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
-                if (lane < count) {
-                    const uint32_t e = doneEntry[first + lane];
-                    const f4v q = doneHit[first + lane];
-                    const uint32_t inst = doneInst[first + lane];
-                    p = load_path(qin, seg + e);
-                    const float4 d = qin.r1[seg + e];
-                    shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv }, sd, gs, tx, aux, p, make_uint4(inst, __float_as_uint(q.w), __float_as_uint(q.y), __float_as_uint(q.z)),
-                                           q.x, V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD);
-                }
-                uint32_t slotT, slotF;
-                wave_reserve2(toTraced, toFresh, &countOut[sq], &countOut[kSubQueues + sq], slotT, slotF);
-                if (toTraced) {
-                    store_path(qout, seg + slotT, p);
-                    qout.r0[seg + slotT] = make_float4(newO.x, newO.y, newO.z, 0.0f);
-                    qout.r1[seg + slotT] = make_float4(newD.x, newD.y, newD.z, INFINITY);
-                }
-                if (toFresh) store_path(qout, seg + (segCap - 1u - slotF), p);
-                nDone = first;
-                if (exhausted && !busy && !nDone) break;
-                continue;
-            }
-            if (exhausted && !busy) break;                                   // nothing in flight, nothing waiting
-            // ---- refill: idle lanes take the next rays of the sub-queue
-            {
-                const unsigned long long idle = ~busy;
-                const uint32_t nIdle = (uint32_t)__popcll(idle);
-                if (!exhausted && (nIdle >= kStreamRefillMin || !busy)) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&cursorIn[sq], nIdle);
-                    base = (uint32_t)__shfl((int)base, 0);
-                    if (base + nIdle >= nT) exhausted = true;
-                    if (qi == ~0u) {
-                        const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
-                        if (e < nT) {
-                            const float4 o = qin.r0[seg + e], d = qin.r1[seg + e];
-                            worldRay[0] = (f4v){ o.x, o.y, o.z, o.w }; worldRay[1] = (f4v){ d.x, d.y, d.z, d.w };
-                            qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16; pendingInst = ~0u;
-                            br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
-                            h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
-                            G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
-                            stack.sp = 0;
-                        }
-                    }
-                }
-            }
-            // ---- walk. One step = one memory round trip for the whole wave: every lane first decides what it will do (visit a node,
-            // test a triangle, look an instance up, enter it), ALL lanes issue their loads together, and only then the sections run.
-            // (With the loads inside the sections a step cost one dependent latency per section, and the four waves of a SIMD could
-            // not cover them: PMC r02_c, VALU 27 % busy, 55 % of wave cycles waiting.)
-            // Node visits are the common work and run every step; triangle tests and instance entries are leaf work that only a few
-            // lanes have at any time: a lane that has both postpones its leaf group on the stack and keeps visiting nodes until
-            // enough lanes wait with leaf work for the section to run with decent lane use (Ylitie et al. 2017, 4.3).
-            bool finished = false;
-            #pragma unroll 1
-            for (uint32_t step = 0; step < kStreamSteps; step++) {
-                const bool live = qi != ~0u && !finished;
-                const bool top = curInst == ~0u;
-                const bool wantNode = live && G.y > 0x00FFFFFFu;
-                const bool leaf = live && T.y != 0u;
-                const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode));
-                const bool doTri = (uint32_t)__popcll(__ballot(leaf && !top)) >= kStreamTriMin || nNode < kStreamNodeMin;
-                const bool doEnter = (uint32_t)__popcll(__ballot(leaf && top)) >= kStreamEnterMin || nNode < kStreamNodeMin;
-                // what this lane does: 0 nothing, 1 node, 2 triangle, 3 instance look-up (order list), 4 instance entry
-                uint32_t act = 0, addr = 0, item = 0;
-                if (leaf && (top ? doEnter : doTri)) {
-                    if (top && pendingInst != ~0u) { act = 4u; addr = bv.instOff16 + pendingInst * kInst16; }
-                    else {
-                        item = T.x + (uint32_t)__builtin_ctz(T.y);
-                        if (top) { act = 3u; }
-                        else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
-                    }
-                } else if (wantNode) {
-                    if (T.y) { stack.push(T); T.y = 0u; pendingInst = ~0u; }  // postpone the leaf group (a looked-up instance belongs to it: look it up again later)
-                    act = 1u;
-                    const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
-                    G.y &= ~(1u << bit);
-                    if (G.y > 0x00FFFFFFu) stack.push(G);
-                    const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
-                    addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
-                }
-                // ---- all loads of the step
-                f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
-                uint32_t ordered = 0;
-                if (act == 3u) ordered = blob.ld32(bv.orderOff16 * 4u + item);
-                if (act == 1u || act == 2u || act == 4u) { L0 = blob.ld(addr); L1 = blob.ld(addr + 1); L2 = blob.ld(addr + 2); }
-                if (act == 1u || act == 4u) { L3 = blob.ld(addr + 3); L4 = blob.ld(addr + 4); }
-                if (act == 4u) L5 = blob.ld(addr + 5);
-                // ---- sections
-                if (act == 1u) {
-                    if (STATS) st.nodes++;
-                    const uint32_t hits = wide_node_hits(L0, L1, L2, L3, L4, br, tmin, h.t);
-                    G = make_uint2(__float_as_uint(L1.x), (hits & 0xFF000000u) | (__float_as_uint(L0.w) >> 24));
-                    T = make_uint2(__float_as_uint(L1.y), hits & 0x00FFFFFFu);
-                }
-                if (act == 2u) {
-                    if (STATS) st.tris++;
-                    float t, u, v;
-                    if (tri_test(rs, br.o, V3(L0.x, L0.y, L0.z), V3(L1.x, L1.y, L1.z), V3(L2.x, L2.y, L2.z), t, u, v))
-                        commit_candidate(ac, __float_as_uint(L2.w), h, tmin, t, u, v, curInst, __float_as_uint(L0.w), __float_as_uint(L1.w), item);
-                }
-                if (act == 3u) pendingInst = ordered;
-                if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
-                    T.y &= T.y - 1u;
-                    const uint32_t ntri = __float_as_uint(L5.y);
-                    if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
-                        const f4v wo = worldRay[0], wd = worldRay[1];
-                        const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
-                        const v3 rd = V3(L0.x * wd.x + L0.y * wd.y + L0.z * wd.z, L1.x * wd.x + L1.y * wd.y + L1.z * wd.z, L2.x * wd.x + L2.y * wd.y + L2.z * wd.z);
-                        rs = ray_setup(rd);
-                        br = box_ray(ro, rd);
-                        nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;
-                        triBase16 = bv.triOff16 + __float_as_uint(L4.w) * kTri16;
-                        stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
-                        const bool single = blas_single_leaf(ntri);
-                        G = root_node_group(single); T = root_tri_group(single, ntri);
-                        curInst = pendingInst;
-                    }
-                    pendingInst = ~0u;
-                }
-                // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
-                if (live && !T.y && G.y <= 0x00FFFFFFu) {
-                    if (stack.sp > 0) {
-                        const uint2 e = stack.pop();
-                        if (e.x == kMarker && e.y == 0u) {                    // leave the BLAS: back to the world-space ray
-                            if (stack.overflow) { finished = true; stack.sp = 0; }
-                            else {
-                                T = stack.pop(); G = stack.pop();
-                                const f4v wo = worldRay[0], wd = worldRay[1];
-                                br = box_ray(V3(wo.x, wo.y, wo.z), V3(wd.x, wd.y, wd.z)); nodeBase16 = bv.nodeOff16; curInst = ~0u;
-                            }
-                        } else if (e.y > 0x00FFFFFFu) G = e;
-                        else T = e;                                           // a postponed leaf group of the current level
-                    } else finished = true;
-                }
-            }
-            // ---- harvest
-            {
-                const unsigned long long fm = __ballot(finished);
-                if (finished) {
-                    const uint32_t e = nDone + (uint32_t)__popcll(fm & ltMask);
-                    const f4v wd = worldRay[1];
-                    const bool hit = h.inst != ~0u && h.t < wd.w;
-                    doneHit[e] = (f4v){ h.t, h.u, h.v, __uint_as_float(h.slot) };
-                    doneInst[e] = hit ? h.inst : ~0u;
-                    doneEntry[e] = qi;
-                    qi = ~0u;
-                }
-                nDone += (uint32_t)__popcll(fm);
-            }
-        }
-        if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
-        if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
-    }
-    for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {
-        const uint32_t local = tile * 256u + threadIdx.x;
-        bool toTraced = false, toFresh = false;
-        PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
-        if (local < nF) {
-            p = load_path(qin, seg + (segCap - 1u - local));
-            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
-        }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
-    }
 }
 
 template <bool STATS>
@@ -1415,7 +1180,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
         // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
         const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
-        if (!lds && !(c.debugFlags & lockStep) && PT_STREAM_SPLIT) {
+        if (!lds && !(c.debugFlags & lockStep)) {
             const bool wt = aux != nullptr;
             for (uint32_t r = 0; r <= rounds; r++) {
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
@@ -1426,23 +1191,10 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 timing_end(c, c.evShade, c.nShade); c.nShade++;
                 if (r == rounds) break;
                 timing_begin(c, c.evExtend, c.nExtend);
-                #define PT_XS(S, W) k_extend_stream<S, W><<<grid, 256, kStreamLdsStack + kStreamLdsRays, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
+                #define PT_XS(S, W) k_extend_stream<S, W><<<grid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
                 if (stats) { if (wt) PT_XS(true, true); else PT_XS(true, false); } else { if (wt) PT_XS(false, true); else PT_XS(false, false); }
                 #undef PT_XS
                 timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
-            }
-            return hipGetLastError();
-        }
-        if (!lds && !(c.debugFlags & lockStep)) {
-            for (uint32_t r = 0; r <= rounds; r++) {
-                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
-                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
-                timing_begin(c, c.evRound, c.nRound);
-                #define PT_STREAM(T, S) k_round_stream<T, S><<<grid, 256, kStreamLds, c.stream>>>(sv, fv, c.frameConstants, tx, c.blob, qin, qout, aux, segCap, cin, cin + 2u * kSubQueues, cout, c.counters)
-                if (c.heapHasTextures) { if (stats) PT_STREAM(true, true); else PT_STREAM(true, false); }
-                else { if (stats) PT_STREAM(false, true); else PT_STREAM(false, false); }
-                #undef PT_STREAM
-                timing_end(c, c.evRound, c.nRound); c.nRound++;
             }
             return hipGetLastError();
         }

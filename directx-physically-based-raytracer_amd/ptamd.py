@@ -61,7 +61,7 @@ class Sharding(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("PrimaryRays", C.c_uint64), ("SecondaryRays", C.c_uint64), ("NodesVisited", C.c_uint64),
                 ("TrianglesTested", C.c_uint64), ("WavefrontIterations", C.c_uint64), ("BvhMismatches", C.c_uint64),
-                ("StackOverflows", C.c_uint64), ("_reserved", C.c_uint64 * 1)]
+                ("StackOverflows", C.c_uint64), ("MaxNodesPerRay", C.c_uint64)]
 
 
 class BlobLayout(C.Structure):

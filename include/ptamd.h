@@ -318,7 +318,7 @@ typedef struct PtCounters {
     uint64_t WavefrontIterations; /* extend/shade rounds launched by the last pt_raytrace_render */
     uint64_t BvhMismatches;       /* PT_DEBUG_BRUTE_FORCE: rays whose BVH result differed from brute force (must be 0) */
     uint64_t StackOverflows;      /* traversal-stack pushes refused for lack of room (must be 0: the builders reject structures that are too deep) */
-    uint64_t _reserved[1];
+    uint64_t MaxNodesPerRay;      /* PT_DEBUG_TRAVERSAL_STATS, scenes beyond LDS: node visits of the longest ray */
 } PtCounters;
 int  pt_reset_counters(PtContext* ctx);
 int  pt_get_counters(PtContext* ctx, PtCounters* out);
