@@ -294,7 +294,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     if (st != PT_OK) return st;
 
     // ---- host side: resolve ids, lay the blob out: [InstanceT x count | nodes: TLAS (reserved), then one piece per referenced
-    // bottom level | triangle packets per piece | instance order list]
+    // bottom level | triangle packets per piece | InstanceT x count once more, in TLAS leaf order]
     const uint32_t tlasNodeCap = wide_node_capacity(count);
     std::vector<uint64_t> pieceIds;
     std::map<uint64_t, uint32_t> pieceOf;
@@ -323,8 +323,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
     }
     const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
-    const size_t orderBytes = ((size_t)count * 4 + 15) / 16 * 16;
-    const size_t total = instBytes + nodeBytes + triBytes + orderBytes;
+    const size_t total = instBytes + nodeBytes + triBytes + instBytes;
     API_ARG(&c, total / 16 < 0xFFFFFFFFull, "scene too large for 32-bit blob addressing");
 
     // ---- capacities: everything is grow-only, so the rebuild of an unchanged scene layout (a dynamic frame) allocates nothing and
@@ -362,7 +361,6 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     hipError_t e = build_tlas_prepare(c.tlas, count);          // node / order arrays of the TLAS (grow-only), known before the jobs that copy them
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
     jobs.push_back(BlobCopy{ c.tlas.nodes, blob + instBytes, sizeof(WideNode) * (size_t)tlasNodeCap / 16 });
-    if (count) jobs.push_back(BlobCopy{ c.tlas.order, blob + instBytes + nodeBytes + triBytes, orderBytes / 16 });
     const size_t jobsOff = (tableOff + tableBytes + 15) / 16 * 16, jobsBytes = sizeof(BlobCopy) * jobs.size();
     up.resize(jobsOff + jobsBytes);
     if (tableBytes) memcpy(up.data() + tableOff, table.data(), tableBytes);
@@ -382,14 +380,15 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     // ---- device side, all in stream order
     e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.stream);
     if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
-    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.blasBounds, dTable, count, (InstanceT*)blob, dJobs, (uint32_t)jobs.size(), c.stream);
+    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.blasBounds, dTable, count, (InstanceT*)blob, c.tlas.order,
+                                                 (InstanceT*)(blob + instBytes + nodeBytes + triBytes), dJobs, (uint32_t)jobs.size(), c.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipEventRecord(c.tlasHeaderEvent, c.stream);
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
     c.tlasHeaderPending = true;
     c.blob.base = (const f4v*)blob;
     c.blob.instOff16 = 0; c.blob.nodeOff16 = (uint32_t)(instBytes / 16); c.blob.triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
-    c.blob.orderOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
+    c.blob.leafInstOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;
@@ -654,7 +653,7 @@ int pt_debug_download_blob(PtContext* ctx, void* host_dst, uint64_t capacity_byt
     if (st != PT_OK) return st;
     if (!c.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "no top-level acceleration structure");
     const BlobView& b = c.blob;
-    *out_layout = PtBlobLayout{ b.instOff16, b.nodeOff16, b.triOff16, b.orderOff16, b.instCount, b.nodeCount, b.triCount, b.bytes };
+    *out_layout = PtBlobLayout{ b.instOff16, b.nodeOff16, b.triOff16, b.leafInstOff16, b.instCount, b.nodeCount, b.triCount, b.bytes };
     if (host_dst) {
         API_ARG(&c, capacity_bytes >= b.bytes, "host buffer smaller than the blob");
         API_HIP(&c, hipMemcpy(host_dst, b.base, b.bytes, hipMemcpyDeviceToHost));

@@ -785,9 +785,18 @@ __global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const 
     const BlasEntry e = table[inst[i].blasSlot];
     t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = e.nodeBase;
     t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = e.triBase;
-    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t.instanceID = inst[i].instanceID; t._pad = 0;
+    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t.instanceID = inst[i].instanceID; t.instanceIndex = i;
     for (int k = 0; k < 12; k++) t.objectToWorld[k] = M[k];
     out[i] = t;
+}
+
+// the same records once more in the order of the TLAS leaves: the TLAS's "triangles"
+__global__ void k_blob_leaf_instances(const InstanceT* __restrict__ api, const uint32_t* __restrict__ order, uint32_t n, InstanceT* __restrict__ leaf)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                 // one 16-byte unit per thread
+    if (t >= n * kInst16) return;
+    const uint32_t p = t / kInst16, part = t - p * kInst16;
+    ((uint4*)leaf)[t] = ((const uint4*)api)[order[p] * kInst16 + part];
 }
 
 // one block per copy job: BLAS nodes / packets and the TLAS pieces into their blob sections (device-to-device, 16 B per lane)
@@ -807,9 +816,10 @@ hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* t
 }
 
 hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
-                                const BlobCopy* jobs, uint32_t njobs, hipStream_t stream)
+                                const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs, hipStream_t stream)
 {
     if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, bounds, table, n, outInst);
+    if (n) k_blob_leaf_instances<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, outLeafInst);
     if (njobs) k_blob_copy<<<dim3(64, njobs < 1024 ? njobs : 1024), 256, 0, stream>>>(jobs, njobs);
     return hipGetLastError();
 }

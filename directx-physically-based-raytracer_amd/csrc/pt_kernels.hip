@@ -838,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     v3 wo = V3(0, 0, 0), wd = V3(0, 0, 1); float wtmax = 0.0f;      // the lane's ray in world space
     constexpr uint32_t kMarker = 0xFFFFFFFFu;
     TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
-    uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, pendingInst = ~0u;
+    uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0;
     float tmin = 0.0f;
     BoxRay br; br.o = V3(0, 0, 0); br.idir = V3(1, 1, 1); br.octinv4 = 0;
     RaySetup rs; rs.c1 = rs.c2 = false; rs.Sx = rs.Sy = rs.Sz = 0.0f;
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                     if (e < nT) {
                         const float4 o = q.r0[seg + e], d = q.r1[seg + e];
                         wo = V3(o.x, o.y, o.z); wd = V3(d.x, d.y, d.z); wtmax = d.w;
-                        qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16; pendingInst = ~0u;
+                        qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16;
                         br = box_ray(V3(o.x, o.y, o.z), V3(d.x, d.y, d.z));
                         h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
                         G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
@@ -886,17 +886,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             const uint32_t most = max(nNode, max(nTri, nEnter));
             const uint32_t lim = max(kStreamMinLanes, most >> kStreamShareShift);
             const bool doNode = nNode >= lim || nNode == most, doTri = nTri >= lim || nTri == most, doEnter = nEnter >= lim || nEnter == most;
-            // what this lane does: 0 nothing, 1 node, 2 triangle, 3 instance look-up (order list), 4 instance entry
+            // what this lane does: 0 nothing, 1 node, 2 triangle, 4 instance entry
             uint32_t act = 0, addr = 0, item = 0;
             if (leaf && (top ? doEnter : doTri)) {
-                if (top && pendingInst != ~0u) { act = 4u; addr = bv.instOff16 + pendingInst * kInst16; }
-                else {
-                    item = T.x + (uint32_t)__builtin_ctz(T.y);
-                    if (top) { act = 3u; }
-                    else { act = 2u; addr = triBase16 + item * kTri16; T.y &= T.y - 1u; }
-                }
+                item = T.x + (uint32_t)__builtin_ctz(T.y);
+                T.y &= T.y - 1u;
+                if (top) { act = 4u; addr = bv.leafInstOff16 + item * kInst16; }
+                else { act = 2u; addr = triBase16 + item * kTri16; }
             } else if (wantNode && doNode) {
-                if (T.y) { stack.push(T); T.y = 0u; pendingInst = ~0u; }  // postpone the leaf group (a looked-up instance belongs to it: look it up again later)
+                if (T.y) { stack.push(T); T.y = 0u; }                     // postpone the leaf group
                 act = 1u;
                 const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
                 G.y &= ~(1u << bit);
@@ -907,8 +905,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             // ---- all loads of the step (a wave-cooperative gather through LDS -- neighbouring lanes fetching neighbouring 16-byte
             // units of one record -- was tried here and lost 30 %: the walk is bound by VALU issue, not by the vector cache)
             f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
-            uint32_t ordered = 0;
-            if (act == 3u) ordered = blob.ld32(bv.orderOff16 * 4u + item);
             if (act == 1u || act == 2u || act == 4u) { L0 = blob.ld(addr); L1 = blob.ld(addr + 1); L2 = blob.ld(addr + 2); }
             if (act == 1u || act == 4u) { L3 = blob.ld(addr + 3); L4 = blob.ld(addr + 4); }
             if (act == 4u) L5 = blob.ld(addr + 5);
@@ -925,9 +921,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 if (tri_test(rs, br.o, V3(L0.x, L0.y, L0.z), V3(L1.x, L1.y, L1.z), V3(L2.x, L2.y, L2.z), t, u, v))
                     commit_candidate(ac, __float_as_uint(L2.w), h, tmin, t, u, v, curInst, __float_as_uint(L0.w), __float_as_uint(L1.w), item);
             }
-            if (act == 3u) pendingInst = ordered;
             if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
-                T.y &= T.y - 1u;
                 const uint32_t ntri = __float_as_uint(L5.y);
                 if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
                     const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
@@ -939,9 +933,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                     stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
                     const bool single = blas_single_leaf(ntri);
                     G = root_node_group(single); T = root_tri_group(single, ntri);
-                    curInst = pendingInst;
+                    curInst = __float_as_uint(L5.w);
                 }
-                pendingInst = ~0u;
             }
             // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
             if (live && !T.y && G.y <= 0x00FFFFFFu) {

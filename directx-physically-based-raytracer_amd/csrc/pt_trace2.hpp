@@ -11,9 +11,10 @@
 //
 // The blob is ONE contiguous allocation addressed in 16-byte units so that the identical code reads it from
 // HBM/L2 (large scenes) or from LDS (scenes that fit: the block stages the blob once, "LDS-staged node /
-// triangle packets"):   [ InstanceT x instCount | WideNode x nodeCount | TriPacket x triCount | instance order u32 x instCount ]
+// triangle packets"):   [ InstanceT x instCount | WideNode x nodeCount | TriPacket x triCount | InstanceT x instCount in TLAS leaf order ]
 // TLAS nodes come first in the node array (root = 0); a BLAS's nodes / packets are contiguous at nodeBase / triBase. Child
-// and triangle references of a node stay relative to their own tree. The TLAS's "triangles" index the instance order list.
+// and triangle references of a node stay relative to their own tree. The TLAS's "triangles" are the instance records of the last
+// section: the same records as the first, in the order of the TLAS leaves, so that entering an instance is one fetch.
 #pragma once
 #include "pt_trace.hpp"
 
@@ -24,14 +25,14 @@ struct alignas(16) InstanceT {        // 144 B = 9 x 16
     float worldToObject[12];
     float boxLo[3]; uint32_t nodeBase;   // padded world AABB of the instance | BLAS root index in the blob node array
     float boxHi[3]; uint32_t triBase;    //                                   | first packet of the BLAS in the blob triangle array
-    uint32_t mask, triCount, instanceID, _pad;
+    uint32_t mask, triCount, instanceID, instanceIndex;   // instanceIndex: position in the API's instance array (InstanceIndex())
     float objectToWorld[12];             // units 6..8: only the shading half of k_round reads them (hit reconstruction)
 };
 static_assert(sizeof(InstanceT) == 144, "layout");
 
 struct BlobView {
     const f4v* base;                   // device pointer to the blob
-    uint32_t instOff16, nodeOff16, triOff16, orderOff16;   // section starts in 16-byte units
+    uint32_t instOff16, nodeOff16, triOff16, leafInstOff16;   // section starts in 16-byte units
     uint32_t instCount, nodeCount, triCount;
     uint32_t bytes;                    // whole blob
 };
@@ -173,15 +174,14 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
     uint2 G = root_node_group(oneInstance), T = root_tri_group(oneInstance, 1u);
     bool tlasDone = !(tmin <= tmax);                                        // an empty interval (a lane without a ray) has nothing to walk
     while (true) {
-        // ---------------- phase A: TLAS walk, collect candidates (the TLAS's "triangles" are entries of the instance order list)
+        // ---------------- phase A: TLAS walk, collect candidates (the TLAS's "triangles" are instance records in leaf order)
         uint32_t nCand = 0;
         while (!tlasDone && nCand < (uint32_t)kCandidates) {
             if (T.y) {
                 const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
                 T.y &= T.y - 1u;
-                const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
-                const f4v mk = blob.ld(bv.instOff16 + x * kInst16 + 5);      // mask, triCount, InstanceID, -
-                if ((__float_as_uint(mk.x) & 0xFFu) && __float_as_uint(mk.y) != 0u) { cand[nCand * 256] = x; nCand++; }
+                const f4v mk = blob.ld(bv.leafInstOff16 + i * kInst16 + 5);  // mask, triCount, InstanceID, InstanceIndex
+                if ((__float_as_uint(mk.x) & 0xFFu) && __float_as_uint(mk.y) != 0u) { cand[nCand * 256] = __float_as_uint(mk.w); nCand++; }
             } else if (G.y > 0x00FFFFFFu) {
                 visit_node<STATS, LDS>(blob, bv.nodeOff16, br, tmin, h.t, G, T, stack, stats);
             } else if (stack.sp > 0) {
@@ -380,10 +380,9 @@ PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const A
             const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
             T.y &= T.y - 1u;
             if (curInst == ~0u) {                                           // a TLAS "triangle": enter the instance
-                const uint32_t x = blob.ld32(bv.orderOff16 * 4u + i);
-                const uint32_t ia = bv.instOff16 + x * kInst16;
+                const uint32_t ia = bv.leafInstOff16 + i * kInst16;
                 const f4v mk = blob.ld(ia + 5);
-                const uint32_t ntri = __float_as_uint(mk.y);
+                const uint32_t ntri = __float_as_uint(mk.y), x = __float_as_uint(mk.w);
                 if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
                     const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
                     ro = V3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w, w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);

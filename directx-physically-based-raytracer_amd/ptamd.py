@@ -65,7 +65,7 @@ class Counters(C.Structure):
 
 
 class BlobLayout(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("InstanceOffset16", "NodeOffset16", "TriangleOffset16", "OrderOffset16",
+    _fields_ = [(n, C.c_uint32) for n in ("InstanceOffset16", "NodeOffset16", "TriangleOffset16", "LeafInstanceOffset16",
                                           "InstanceCount", "NodeCount", "TriangleCount", "Bytes")]
 
 

@@ -8,7 +8,7 @@ import numpy as np
 NODE_DT = np.dtype([("origin", "<f4", 3), ("exp", "u1", 3), ("imask", "u1"), ("childBase", "<u4"), ("triBase", "<u4"), ("meta", "u1", 8),
                     ("qlox", "u1", 8), ("qloy", "u1", 8), ("qloz", "u1", 8), ("qhix", "u1", 8), ("qhiy", "u1", 8), ("qhiz", "u1", 8)])
 INST_DT = np.dtype([("worldToObject", "<f4", 12), ("boxLo", "<f4", 3), ("nodeBase", "<u4"), ("boxHi", "<f4", 3), ("triBase", "<u4"),
-                    ("mask", "<u4"), ("triCount", "<u4"), ("instanceID", "<u4"), ("_pad", "<u4"), ("objectToWorld", "<f4", 12)])
+                    ("mask", "<u4"), ("triCount", "<u4"), ("instanceID", "<u4"), ("instanceIndex", "<u4"), ("objectToWorld", "<f4", 12)])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("geom", "<u4"), ("v1", "<f4", 3), ("prim", "<u4"), ("v2", "<f4", 3), ("flags", "<u4")])
 assert NODE_DT.itemsize == 80 and INST_DT.itemsize == 144 and TRI_DT.itemsize == 48
 
@@ -17,7 +17,12 @@ def split(layout, buf):
     inst = buf[layout.InstanceOffset16 * 16:][:layout.InstanceCount * 144].view(INST_DT)
     nodes = buf[layout.NodeOffset16 * 16:][:layout.NodeCount * 80].view(NODE_DT)
     tris = buf[layout.TriangleOffset16 * 16:][:layout.TriangleCount * 48].view(TRI_DT)
-    order = buf[layout.OrderOffset16 * 16:][:layout.InstanceCount * 4].view("<u4")
+    leaf = buf[layout.LeafInstanceOffset16 * 16:][:layout.InstanceCount * 144].view(INST_DT)
+    order = leaf["instanceIndex"].astype(np.uint32)             # the TLAS's items: the instance records once more, in leaf order
+    if len(inst):
+        assert np.array_equal(inst["instanceIndex"], np.arange(len(inst), dtype=np.uint32)), "instance records are not in API order"
+        if sorted(order.tolist()) == list(range(len(inst))):
+            assert leaf.tobytes() == inst[order].tobytes(), "leaf-order instance records differ from the API-order ones"
     return inst, nodes, tris, order
 
 
