@@ -10,7 +10,8 @@ total work is fixed as N grows => "scaling": "strong". Rays = primary (G-buffer)
 traced, counted on the device. One JSON line is printed by rank 0.
 
 Extra objects in the line (DESIGN.md "Measurement"):
-  roofline      dominant kernel of the frame: algorithmic bytes / HIP-event time of its launches vs 8 TB/s HBM
+  roofline      algorithmic HBM bytes of a frame / one-frame latency vs 8 TB/s HBM, the dominant kernel on its own (per-launch HIP
+                events, single stream), the pipelined figure, BVH bytes by where they are served from, PMC traffic and VALU issue
   cpu_baseline  the CPU oracle (oracle/, OpenMP) timed on this host on a bounded row slab of the same frame
 """
 import argparse
@@ -35,7 +36,20 @@ WORKLOADS = {
     "c4": ("cornell", 3840, 2160, 16, 16, "Cornell Box 3840x2160 16spp 16 bounces (BASELINE configs[3])"),
     "c5": ("grid", 1920, 1080, 4, 8, "10k instances two-level BVH 1920x1080 4spp 8 bounces (BASELINE configs[4])"),
     "c1": ("cornell_lambert", 256, 256, 1, 2, "Cornell Box 256x256 1spp 2 bounces Lambertian only (BASELINE configs[0])"),
+    # not a BASELINE config: the per-frame cost of a dynamic scene (skinning, in-place BLAS refit, TLAS rebuild), Scene.ixx:233-280,327-380
+    "dynamic": ("dynamic", 1920, 1080, 1, 4, "1024 static instances + one skinned 2048-triangle mesh, 1920x1080 1spp 4 bounces, structures updated every frame"),
 }
+
+
+def source_hash():
+    """hash of the kernel sources a libptamd.so is built from: PMC figures in profiles/traffic.json are only quoted for the same sources"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "directx-physically-based-raytracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_scene(kind, aspect, S):
@@ -47,6 +61,8 @@ def make_scene(kind, aspect, S):
         return S.sponza_scale(aspect=aspect), 0
     if kind == "grid":
         return S.instanced_grid(n=100, aspect=aspect), 0
+    if kind == "dynamic":
+        return S.dynamic_instanced(n=32, aspect=aspect), 0
     raise ValueError(kind)
 
 
@@ -174,17 +190,21 @@ def main():
 
     kind, W, H, spp, bounces, desc = WORKLOADS[args.workload]
     scene, ext = make_scene(kind, W / H, S)
+    dynamic = kind == "dynamic"
+    if dynamic:
+        args.inflight = 1                                       # every frame depends on the structures the previous one updated
     max_rows = max(P.local_rows(H, r, world, BAND) for r in range(world))
     offsets = (np.arange(world, dtype=np.uint64) * np.uint64(max_rows * W * 8))
 
     class Lane:
-        """One frame in flight: its own HIP stream, library context (queues, BVH copy) and G-buffer textures."""
-        def __init__(self):
+        """One frame in flight: its own HIP stream, library context (path queues, counters) and G-buffer textures. The scene -- vertex
+        and index buffers, acceleration structures, traversal copy -- is built ONCE, by lane 0; the others view it (pt_share_scene)."""
+        def __init__(self, owner=None):
             self.stream = torch.cuda.Stream(device)
             with torch.cuda.stream(self.stream):
                 self.ctx = P.DeviceContext(local_rank, stream=self.stream.cuda_stream)
                 self.ctx.set_sharding(rank, args.emulate_world if args.emulate_world else world, BAND)
-                self.scene = P.Scene(self.ctx, scene, device)
+                self.scene = P.Scene(self.ctx, scene, device) if owner is None else P.SharedScene(self.ctx, owner.scene)
                 self.renderer = P.Renderer(self.ctx, self.scene, W, H)
                 if collective:                                  # equal-sized gather pieces
                     self.renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
@@ -194,17 +214,31 @@ def main():
                 self.gathered = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and collective) else None
             self.stream.synchronize()
 
-    lanes = [Lane() for _ in range(max(1, args.inflight))]
+    lanes = [Lane()]
+    lanes += [Lane(lanes[0]) for _ in range(max(1, args.inflight) - 1)]
     ctx = lanes[0].ctx
     BASE_FLAGS = 0x10 if args.unfused else 0                   # PT_DEBUG_UNFUSED_ROUNDS
     for lane in lanes:
         lane.ctx.set_debug_flags(BASE_FLAGS)
+    dyn_events = []
 
     def step(frame_index):
         lane = lanes[frame_index % len(lanes)]
         gs = S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=frame_index, ext_flags=ext)
         with torch.cuda.stream(lane.stream):
-            lane.renderer.render(gs)
+            if dynamic:                                         # Scene::Tick + SkinSkeletalMeshes + CreateAccelerationStructures, every frame
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                bar = scene.nodes[-1].meshes[0]
+                ev[0].record(lane.stream)
+                lane.scene.SkinSkeletalMeshes(bar, S.bar_pose(30.0 * np.sin(0.2 * frame_index), 0.05 * (frame_index % 7)))
+                ev[1].record(lane.stream)
+                lane.scene.UpdateAccelerationStructures(len(scene.nodes) - 1)
+                ev[2].record(lane.stream)
+                lane.renderer.render(gs)
+                ev[3].record(lane.stream)
+                dyn_events.append(ev)
+            else:
+                lane.renderer.render(gs)
             if collective:
                 SH.gather_to_root(lane.renderer.textures["Radiance"], rank, world, dist, out=lane.gathered)
                 if rank == 0:
@@ -221,12 +255,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    timing = world == 1 and not collective and not args.emulate_world and not args.no_kernel_timing          # HIP events around every extend / shade launch (library side)
+    dyn_events.clear()
     for lane in lanes:
         lane.ctx.reset_counters()
-        if timing:
-            lane.ctx.enable_kernel_timing(True)
     barrier()
+    # ---- the timed region: K steps, frames in flight on their own streams, hipGraph replay (no per-launch events here: an event pair
+    # around a launch on one stream also spans the other lanes' kernels; kernel durations are measured in the single-stream pass below)
     t0 = time.perf_counter()
     for i in range(args.steps):
         gs = step(args.warmup + i)
@@ -234,9 +268,6 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     counters = [lane.ctx.counters() for lane in lanes]
-    kts = [lane.ctx.kernel_timing() for lane in lanes] if timing else None
-    for lane in lanes:
-        lane.ctx.enable_kernel_timing(False)
     primary = sum(c.PrimaryRays for c in counters); secondary = sum(c.SecondaryRays for c in counters)
 
     rays_local = float(primary + secondary)
@@ -251,6 +282,7 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        acc = ctx.accel_stats()
         result = {
             "metric": "Mrays/s per GPU + frames/s at 1080p, Cornell Box 4spp/8bounce",
             "value": rays_total / elapsed / 1e6, "unit": "Mrays/s",
@@ -259,99 +291,112 @@ def main():
             "frames_per_s": args.steps / elapsed, "mrays_per_s_per_gpu": rays_total / elapsed / 1e6 / world,
             "rays_per_frame": rays_total / args.steps, "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
             "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes),
-                       "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
+                       "scene_copies_per_gpu": 1, "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
+                       "bvh": {"node_bytes": acc.NodeSizeBytes, "nodes_total_bytes": acc.NodeBytes, "triangles_total_bytes": acc.TriangleBytes,
+                               "bottom_level_depth": acc.MaxBottomLevelDepth, "top_level_depth": acc.TopLevelDepth, "traversal_copy_bytes": acc.BlobBytes},
                        "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "rccl_world_size": dist.get_world_size() if collective else 1,
-                       "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py)"},
+                       "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py, tests/test_gpu_fullscale.py)"},
         }
+        if dynamic and dyn_events:
+            ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in dyn_events[-args.steps:]])
+            result["dynamic"] = {"skin_ms": float(ms[:, 0].mean()), "update_and_top_level_ms": float(ms[:, 1].mean()), "render_ms": float(ms[:, 2].mean()),
+                                 "note": "HIP events on the frame's stream: pt_skin_mesh | pt_update_bottom_level (in-place refit) + pt_build_top_level | G-buffer + path tracer"}
 
-    # ---- roofline of the dominant kernel (N = 1): one extra frame with traversal statistics for B_bvh
-    if rank == 0 and timing:
-        kt = {k: sum(x[k] for x in kts) for k in kts[0]}
-        ctx.set_debug_flags(1 | BASE_FLAGS)
-        ctx.reset_counters()
-        with torch.cuda.stream(lanes[0].stream):
-            lanes[0].renderer.render(gs)
+    # ---- roofline (N = 1). Everything below runs AFTER the timed region, on lane 0 alone.
+    instrumented = world == 1 and not collective and not args.emulate_world and not args.no_kernel_timing and not dynamic
+    if rank == 0 and instrumented:
+        def frames_on_lane0(n, first):
+            with torch.cuda.stream(lanes[0].stream):
+                for i in range(n):
+                    lanes[0].renderer.render(S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=first + i, ext_flags=ext))
+            torch.cuda.synchronize(device)
+
+        # (1) one frame at a time, graph replay, the GPU to itself: the latency figure next to the pipelined throughput
+        frames_on_lane0(2, args.warmup)
+        t1 = time.perf_counter(); frames_on_lane0(args.steps, args.warmup); latency_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        # (2) traversal statistics of one frame (nodes / triangles actually fetched)
+        ctx.set_debug_flags(1 | BASE_FLAGS); ctx.reset_counters()
+        frames_on_lane0(1, args.warmup + args.steps - 1)
         cs = ctx.counters()
         ctx.set_debug_flags(BASE_FLAGS)
-        # one more instrumented pass on ONE lane: with several frames in flight an event pair around a launch also spans
-        # the other lanes' kernels, so the per-launch durations above are upper bounds. Here each launch has the GPU alone.
+        # (3) per-launch HIP events (recorded by the library on the stream the kernels run on), K frames, single stream
         ctx.reset_counters(); ctx.enable_kernel_timing(True)
-        with torch.cuda.stream(lanes[0].stream):
-            for i in range(args.steps):
-                lanes[0].renderer.render(S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=args.warmup + i, ext_flags=ext))
-        torch.cuda.synchronize(device)
-        ks = ctx.kernel_timing(); serial_secondary = float(ctx.counters().SecondaryRays)
+        frames_on_lane0(args.steps, args.warmup)
+        ks = ctx.kernel_timing(); c1 = ctx.counters()
         ctx.enable_kernel_timing(False)
-        rays_frame = max(1, cs.SecondaryRays)
-        node_b, tri_b = 64, 48
-        bvh_bytes_per_ray = (cs.NodesVisited * node_b + cs.TrianglesTested * tri_b) / float(cs.PrimaryRays + cs.SecondaryRays)
-        sec_rays = secondary_total
-        # algorithmic bytes per secondary ray (DESIGN.md / SURVEY 8d). Fused round (the product path): ray read 32 + path state
-        # 48 r + 48 w + ray write 32 + hit geometry 108 + B_bvh = 268 + B_bvh (the 16 B hit record stays in registers).
-        # Two-kernel form (--unfused): extend = ray read 32 + hit write 16 + B_bvh; shade = hit read 16 + ray dir 16 + state 96 + ray write 32 + geometry 108
-        STATE = {"k_round": 268.0, "k_extend": 48.0, "k_shade": 252.0}
-        WITH_BVH = {"k_round", "k_extend"}
+        solo_secondary, solo_primary = float(c1.SecondaryRays), float(c1.PrimaryRays)
 
-        def kernel_table(t, rays):
-            tab = {}
-            for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
-                if t.get(key + "_launches", 0):
-                    per_ray = STATE[name] + (bvh_bytes_per_ray if name in WITH_BVH else 0.0)
-                    tab[name] = {"ms": t[key + "_ms"], "launches": t[key + "_launches"], "bytes": rays * per_ray, "state_bytes": rays * STATE[name]}
-            return tab
+        all_rays = float(cs.PrimaryRays + cs.SecondaryRays)
+        bvh_bytes_per_ray = (cs.NodesVisited * acc.NodeSizeBytes + cs.TrianglesTested * acc.TriangleSizeBytes) / all_rays
+        blob_in_lds = acc.BlobBytes <= 40 * 1024               # kBlobLdsMax: the traversal copy is staged into LDS by every block
+        # Algorithmic HBM bytes. Per secondary ray of the fused round: ray read 32 + path state 48 r + 48 w + ray
+        # write 32 + hit geometry 108 = 268 (the hit record stays in registers). Two-kernel form: traversal = ray read 32 + hit record
+        # write 16; shading = hit read 16 + ray direction 16 + state 96 + ray write 32 + geometry 108 = 268. BVH bytes count as HBM
+        # bytes only when the traversal copy does not fit LDS; otherwise they are reported as lds_served and never as HBM traffic.
+        STATE = {"k_round": 268.0, "k_extend": 48.0, "k_shade": 268.0}
+        hbm_bvh = 0.0 if blob_in_lds else bvh_bytes_per_ray
 
         def gbps(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
-        kernels = kernel_table(kt, sec_rays)
+        kernels = {}
+        for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
+            if ks.get(key + "_launches", 0):
+                per_ray = STATE[name] + (hbm_bvh if name in ("k_round", "k_extend") else 0.0)
+                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray}
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         kd = kernels[dom]
-        achieved = gbps(kd["bytes"], kd["ms"])
-        traffic = None
+        # step level: every byte a frame has to move through HBM by construction of the data layout
+        hit_pixels = W * H                                       # upper bound (camera inside the scene: every primary ray hits on C2)
+        frame_bytes = (W * H * 63.0 + hit_pixels * 64.0                      # G-buffer stores; k_pt_init: Position.w read + fresh state written
+                       + solo_secondary / args.steps * (268.0 + hbm_bvh)     # traced entries
+                       + hit_pixels * spp * (47.0 + 48.0 + 48.0 + 32.0)      # fresh entries: G-buffer re-read, state r + w, first ray written
+                       + W * H * 8.0)                                        # radiance out
+        step_achieved = gbps(frame_bytes, latency_ms)
+        traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.workload, {}).get(dom)
+                ent = tj.get(args.workload, {})
+                if ent.get("source_hash") == source_hash():
+                    traffic = ent.get(dom); valu = ent.get("valu")
+                else:
+                    traffic_note = "profiles/traffic.json was taken from other kernel sources than this build: PMC figures omitted"
             except Exception:
                 traffic = None
+        props = torch.cuda.get_device_properties(device)
+        clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
         result["roofline"] = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "state_only": {"achieved": gbps(kd["state_bytes"], kd["ms"]), "frac": gbps(kd["state_bytes"], kd["ms"]) / HBM_PEAK_GBS,
-                           "note": "queue/state bytes only, without B_bvh (BVH bytes of an LDS- or cache-resident scene never reach HBM)"},
-            "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
-            "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
-            "bvh_bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / float(cs.PrimaryRays + cs.SecondaryRays),
-            "tris_per_ray": cs.TrianglesTested / float(cs.PrimaryRays + cs.SecondaryRays),
-            "other_kernel": {k: {"ms_total": v["ms"], "GBps": gbps(v["bytes"], v["ms"])} for k, v in kernels.items() if k != dom},
-            "note": "HIP-event time summed over every launch of the timed steps (all frames in flight, so a launch shares the GPU with "
-                    "the other lanes' kernels); bytes = algorithmic bytes per secondary ray x rays (DESIGN.md)",
+            "bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "definition": "achieved = algorithmic HBM bytes of one frame / latency_ms_one_frame (single stream, graph replay); "
+                          "dominant_kernel.* = the same for that kernel alone, from its per-launch HIP events in the single-stream pass",
+            "hbm_bytes_per_frame": frame_bytes, "latency_ms_one_frame": latency_ms,
+            "dominant_kernel": {"name": dom, "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
+                                "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
+                                "achieved": gbps(kd["bytes"], kd["ms"]), "frac": gbps(kd["bytes"], kd["ms"]) / HBM_PEAK_GBS},
+            "other_kernels": {k: {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": gbps(v["bytes"], v["ms"])}
+                              for k, v in kernels.items() if k != dom},
+            "pipelined": {"frames_in_flight": len(lanes), "ms_per_step": ms_per_step, "achieved": gbps(frame_bytes, ms_per_step),
+                          "frac": gbps(frame_bytes, ms_per_step) / HBM_PEAK_GBS},
+            "bvh": {"bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / all_rays, "tris_per_ray": cs.TrianglesTested / all_rays,
+                    "longest_walk_nodes": cs.MaxNodesPerRay or None,
+                    "served_from": "LDS (the traversal copy is staged by every block): not HBM traffic" if blob_in_lds else "L2 / Infinity Cache / HBM: counted in the HBM bytes above"},
         }
-        # the bound that actually binds: VALU issue. Instruction count per frame from the committed PMC
-        # profile, issue peak = CUs x 4 SIMDs x clock / 4 cycles per wave64 instruction
-        try:
-            vj = json.load(open(tpath)).get(args.workload + "_valu")
-        except Exception:
-            vj = None
-        if vj:
-            props = torch.cuda.get_device_properties(device)
-            peak_issue = props.multi_processor_count * 4 * 2.4e9 / 4.0
-            issued = vj["wave_instructions_per_frame"] * (args.steps / elapsed)
-            result["roofline"]["valu_issue"] = {"wave_instructions_per_frame": vj["wave_instructions_per_frame"], "issued_per_s": issued,
-                                                 "peak_per_s": peak_issue, "frac": issued / peak_issue,
-                                                 "note": "SQ_INSTS_VALU from profiles/ x frames/s of this run; 2.4 GHz engine clock"}
-        serial = {}
-        for name, v in kernel_table(ks, serial_secondary).items():
-            g = gbps(v["bytes"], v["ms"]); so = gbps(v["state_bytes"], v["ms"])
-            serial[name] = {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": g, "frac": g / HBM_PEAK_GBS,
-                            "state_only": {"achieved": so, "frac": so / HBM_PEAK_GBS}}
-        result["roofline"]["one_frame_in_flight"] = dict(serial, note="same K steps repeated on a single stream after the timed region: "
-                                                         "per-launch durations without other lanes' kernels inside the event pair "
-                                                         "(these are the figures rocprofv3's per-kernel averages agree with)")
-        del rays_frame
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world:
+        if traffic_note:
+            result["roofline"]["traffic_note"] = traffic_note
+        # the bound that actually binds: VALU issue, one wave64 instruction per 4 cycles per SIMD
+        if valu:
+            peak_issue = props.multi_processor_count * 4 * clock_hz / 4.0
+            issued = valu["wave_instructions_per_frame"] / (latency_ms * 1e-3)
+            result["roofline"]["valu_issue"] = {"wave_instructions_per_frame": valu["wave_instructions_per_frame"], "issued_per_s": issued,
+                                                 "peak_per_s": peak_issue, "frac": issued / peak_issue, "clock_hz": clock_hz,
+                                                 "pipelined_frac": valu["wave_instructions_per_frame"] / (ms_per_step * 1e-3) / peak_issue,
+                                                 "note": "SQ_INSTS_VALU of every kernel of a frame (profiles/, same kernel sources) / frame time"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world and not dynamic:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
 
     sys.stdout.flush()

@@ -64,6 +64,7 @@ void pt_destroy(PtContext* ctx)
     hipSetDevice(c.device);
     hipStreamSynchronize(c.stream);
     for (auto& kv : c.blas) free_blas(kv.second);
+    if (c.sceneOwner) { c.sceneOwner->borrowers--; c.tlas = Tlas(); c.blobDev = nullptr; }       // views: the owner frees them
     free_tlas(c.tlas);
     if (c.heapDev) hipFree(c.heapDev);
     if (c.srgbLutDev) hipFree(c.srgbLutDev);
@@ -272,6 +273,7 @@ int pt_release_bottom_level(PtContext* ctx, uint64_t blas_id)
     Context& c = ctx->c;
     auto it = c.blas.find(blas_id);
     API_ARG(&c, it != c.blas.end(), "unknown bottom-level id");
+    API_ARG(&c, c.borrowers == 0, "other contexts view this context's scene (pt_share_scene)");
     hipStreamSynchronize(c.stream);
     // the live top level may refer to it (instance records hold its arrays): that top level dies with it, and a render
     // before the next pt_build_top_level answers PT_ERROR_NOT_READY instead of reading freed memory
@@ -289,7 +291,9 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     Context& c = ctx->c;
     API_ARG(&c, descs || count == 0, "descs is NULL");
+    API_ARG(&c, c.borrowers == 0, "other contexts view this context's scene (pt_share_scene): destroy or re-point them before rebuilding");
     API_HIP(&c, hipSetDevice(c.device));
+    if (c.sceneOwner) { c.sceneOwner->borrowers--; c.sceneOwner = nullptr; c.tlas = Tlas(); c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{}; drop_tlas(c); }
     int st = poll_tlas_header(c, false);
     if (st != PT_OK) return st;
 
@@ -398,6 +402,34 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     return PT_OK;
 }
 
+int pt_share_scene(PtContext* ctx, PtContext* source)
+{
+    if (!ctx || !source || ctx == source) return PT_ERROR_INVALID_ARGUMENT;
+    Context& c = ctx->c; Context& s = source->c;
+    API_ARG(&c, c.device == s.device, "both contexts must live on the same device");
+    API_ARG(&c, c.borrowers == 0, "other contexts view this context's scene");
+    API_ARG(&c, !s.sceneOwner, "the source views another context's scene itself: share from the owner");
+    API_HIP(&c, hipSetDevice(c.device));
+    API_HIP(&c, hipStreamSynchronize(s.stream));
+    API_HIP(&c, hipStreamSynchronize(c.stream));
+    int st = poll_tlas_header(s, true);
+    if (st != PT_OK) return fail(&c, st, s.lastError);
+    if (!s.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "the source context has no top-level acceleration structure");
+    if (c.sceneOwner) c.sceneOwner->borrowers--;
+    else { free_tlas(c.tlas); if (c.blobDev) hipFree(c.blobDev); }
+    c.blobDev = nullptr; c.blobCapacity = 0;
+    c.tlas = Tlas();
+    c.tlas.instances = s.tlas.instances; c.tlas.instanceCount = s.tlas.instanceCount; c.tlas.triangleCount = s.tlas.triangleCount;   // views
+    c.blob = s.blob;
+    c.tlasObjectEnd = s.tlasObjectEnd; c.maxBlasDepth = s.maxBlasDepth;
+    c.heapHost = s.heapHost; c.heapDirty = true;                            // the descriptor table is copied (each context uploads its own)
+    c.objects = s.objects; c.objectCount = s.objectCount; c.instanceData = s.instanceData; c.instanceDataCount = s.instanceDataCount;
+    c.sceneOwner = &s; s.borrowers++;
+    c.tlasBlasIds.clear(); c.tlasHeaderPending = false; c.validated = false;
+    c.haveTlas = true;
+    return PT_OK;
+}
+
 int pt_get_accel_stats(PtContext* ctx, PtAccelStats* out)
 {
     if (!ctx || !out) return PT_ERROR_INVALID_ARGUMENT;
@@ -413,7 +445,8 @@ int pt_get_accel_stats(PtContext* ctx, PtAccelStats* out)
     out->NodeSizeBytes = sizeof(WideNode); out->TriangleSizeBytes = sizeof(TriPacket);
     uint64_t nb = (uint64_t)wide_node_capacity(c.tlas.instanceCount) * sizeof(WideNode), tb = 0;
     for (auto& kv : c.blas) { nb += (uint64_t)kv.second.nodeCount * sizeof(WideNode); tb += (uint64_t)kv.second.triCount * sizeof(TriPacket); out->MaxBottomLevelDepth = std::max(out->MaxBottomLevelDepth, kv.second.depth); }
-    out->BlobBytes = c.blob.bytes;
+    out->BlobBytes = c.sceneOwner ? 0 : c.blob.bytes;          // a view holds no memory of its own
+    out->SharedScene = c.sceneOwner ? 1u : 0u;
     if (c.tlasHeaderHost && !c.tlasHeaderPending) out->TopLevelDepth = c.tlasHeaderHost->depth;
     out->NodeBytes = nb; out->TriangleBytes = tb;
     return PT_OK;

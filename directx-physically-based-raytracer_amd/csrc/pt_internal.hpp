@@ -104,6 +104,8 @@ struct Context {
 
     std::map<uint64_t, Blas> blas; uint64_t nextBlasId = 1;
     Tlas tlas; bool haveTlas = false;
+    Context* sceneOwner = nullptr;                    // pt_share_scene: tlas / blob below are views of that context's, never freed here
+    int borrowers = 0;                                // contexts viewing THIS context's scene
     std::vector<uint64_t> tlasBlasIds;                // bottom levels the live TLAS refers to (pt_release_bottom_level checks)
     std::vector<uint8_t> tlasUploadHost; void* tlasUploadDev = nullptr; size_t tlasUploadCap = 0;   // InstanceSource | BlasEntry | BlobCopy
     WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check

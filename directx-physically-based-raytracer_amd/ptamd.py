@@ -21,7 +21,7 @@ _LIB = None
 EXPORTS = [
     "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync",
     "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
-    "pt_build_top_level", "pt_get_accel_stats", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
+    "pt_build_top_level", "pt_get_accel_stats", "pt_share_scene", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
     "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_debug_download_blob", "pt_debug_trace_ray", "pt_enable_kernel_timing", "pt_get_kernel_timing", "pt_get_round_timing",
@@ -73,7 +73,7 @@ class AccelStats(C.Structure):
     _fields_ = [("InstanceCount", C.c_uint32), ("BottomLevelCount", C.c_uint32), ("TriangleCount", C.c_uint64),
                 ("NodeBytes", C.c_uint64), ("TriangleBytes", C.c_uint64), ("NodeSizeBytes", C.c_uint32),
                 ("TriangleSizeBytes", C.c_uint32), ("MaxBottomLevelDepth", C.c_uint32), ("TopLevelDepth", C.c_uint32),
-                ("BlobBytes", C.c_uint64)]
+                ("BlobBytes", C.c_uint64), ("SharedScene", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 def load_library():
@@ -102,6 +102,7 @@ def load_library():
         lib.pt_skin_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         lib.pt_build_top_level.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         lib.pt_get_accel_stats.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pt_share_scene.argtypes = [C.c_void_p, C.c_void_p]
         for f in (lib.pt_set_camera, lib.pt_set_scene_data, lib.pt_set_sharding, lib.pt_raytrace_set_constants,
                   lib.pt_raytrace_render, lib.pt_get_counters):
             f.argtypes = [C.c_void_p, C.c_void_p]
@@ -228,6 +229,21 @@ def to_device(arr, device):
     return torch.from_numpy(raw.copy()).to(device)
 
 
+class SharedScene:
+    """A second context's view of a Scene built on another context of the same GPU (pt_share_scene): frames in flight on separate
+    streams render one copy of the scene. Holds a reference to the owning Scene so that it outlives the view."""
+
+    def __init__(self, ctx, owner):
+        self.ctx, self.owner, self.desc, self.device = ctx, owner, owner.desc, owner.device
+        ctx.check(ctx.lib.pt_share_scene(ctx.handle, owner.ctx.handle))
+
+    def GetTopLevelAccelerationStructure(self):
+        return self.ctx.handle
+
+    def close(self):
+        pass
+
+
 class Scene:
     """Device-side scene: the part of Scene (Source/Scene.ixx:75-403) and App::UpdateScene
     (Source/App.cpp:1016-1074) that feeds the hot path: vertex/index buffers, descriptor heap,
@@ -329,16 +345,20 @@ class Scene:
         self._build_top_level()
 
     def _build_top_level(self):
+        """instance descs as Scene::CreateAccelerationStructures fills them (Scene.ixx:365-377). The array is kept: a dynamic frame
+        re-submits it as it is (transforms of the static instances do not move; update_instance_transform() for those that do)."""
         ctx, scene, lib = self.ctx, self.desc, self.ctx.lib
         n = len(scene.objects)
-        descs = (InstanceDesc * max(1, n))()
-        for i in range(n):                                        # Scene.ixx:365-377
-            t = np.ascontiguousarray(scene.instance_data[i]["ObjectToWorld"], np.float32).reshape(-1)
-            descs[i].Transform = (C.c_float * 12)(*t.tolist())
-            descs[i].InstanceID = int(scene.instance_ids[i])
-            descs[i].InstanceMask = int(scene.instance_masks[i])
-            descs[i].AccelerationStructure = self.blas_ids[int(scene.instance_blas[i])]
-        ctx.check(lib.pt_build_top_level(ctx.handle, C.addressof(descs), n, 0x4))
+        if getattr(self, "_descs", None) is None or len(self._descs) != max(1, n) or self._descs_ids != list(self.blas_ids):
+            descs = (InstanceDesc * max(1, n))()
+            tr = np.ascontiguousarray(scene.instance_data["ObjectToWorld"], np.float32).reshape(n, 12) if n else np.zeros((0, 12), np.float32)
+            for i in range(n):
+                descs[i].Transform = (C.c_float * 12)(*tr[i].tolist())
+                descs[i].InstanceID = int(scene.instance_ids[i])
+                descs[i].InstanceMask = int(scene.instance_masks[i])
+                descs[i].AccelerationStructure = self.blas_ids[int(scene.instance_blas[i])]
+            self._descs, self._descs_ids = descs, list(self.blas_ids)
+        ctx.check(lib.pt_build_top_level(ctx.handle, C.addressof(self._descs), n, 0x4))
 
     def GetTopLevelAccelerationStructure(self):
         return self.ctx.handle        # the context owns the single TLAS

@@ -554,6 +554,19 @@ def instanced_grid(n=100, seed=42, aspect=16 / 9, subdiv=2):
     return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, -1)), name="instanced_grid").finalize()
 
 
+def dynamic_instanced(n=32, aspect=16 / 9, segments=256):
+    """n*n static instances + ground + light (instanced_grid) and one skinned column in front of the camera: the per-frame work of a
+    dynamic scene -- skinning, bottom-level update of the skinned mesh node, top-level rebuild over ~1 k instances (bench.py
+    --workload dynamic)."""
+    sc = instanced_grid(n=n, aspect=aspect)
+    bar = skinned_bar(segments=segments)
+    sc.nodes.append(MeshNode([bar]))
+    sc.objects.append(RenderObject(len(sc.nodes) - 1, trs((0.0, 0.0, 1.2), 15.0, (1.0, 1.6, 1.0))))
+    sc.scene_data = make_scene_data((0.05, 0.06, 0.08, 1), is_static=False)
+    sc.name = "dynamic_instanced"
+    return sc.finalize()
+
+
 def graphics_settings(width, height, spp=1, bounces=8, frame_index=0, russian_roulette=True, ext_flags=0,
                       throughput_threshold=1e-3):
     """Raytracing::GraphicsSettings with the reference defaults (MyAppData.h:182-188, Raytracing.ixx:33)."""

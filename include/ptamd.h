@@ -250,9 +250,16 @@ typedef struct PtAccelStats {
     uint64_t NodeBytes, TriangleBytes;    /* device memory held by BVH nodes / triangle packets */
     uint32_t NodeSizeBytes, TriangleSizeBytes;   /* 80 (compressed 8-wide node) / 48 */
     uint32_t MaxBottomLevelDepth, TopLevelDepth; /* levels of 8-wide nodes */
-    uint64_t BlobBytes;                   /* the traversal copy: instances + every referenced bottom level + top level */
+    uint64_t BlobBytes;                   /* the traversal copy: instances + every referenced bottom level + top level (0 for a view) */
+    uint32_t SharedScene, _pad;           /* 1: this context views another context's scene (pt_share_scene) */
 } PtAccelStats;
 int  pt_get_accel_stats(PtContext* ctx, PtAccelStats* out);           /* synchronises */
+
+/* Frames in flight: several contexts (one HIP stream, one set of path queues each) rendering the SAME static scene need one copy
+ * of it. After this call `ctx` renders from `source`'s acceleration structures, descriptor table and object / instance data, read-only
+ * (reference: one Scene, App.cpp:372-374, whatever the number of frames the swap chain keeps in flight). `ctx` owns none of it:
+ * `source` must outlive the sharing, and refuses to rebuild or release its structures while it is viewed. Synchronises both streams. */
+int  pt_share_scene(PtContext* ctx, PtContext* source);
 
 /* ------------------------------------------------------------------------------------------
  * per-frame inputs (reference: the GPUBuffers slots the caller fills before each Render,
