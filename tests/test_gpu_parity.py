@@ -473,3 +473,111 @@ def test_error_behaviour(ptamd, pkg):
         assert ctx.accel_stats().InstanceCount == 0
     finally:
         ctx.close()
+
+
+def test_shared_scene_frames_in_flight(gpu, ptamd, pkg):
+    """pt_share_scene: three contexts on three streams render from ONE copy of the scene (built by the first). Every frame equals the
+    same frame rendered alone; the views hold no structure memory; the owner refuses to rebuild or release while it is viewed."""
+    import ctypes as C
+    import torch
+    S = pkg.scenes
+    W, H = 320, 180
+    scene = S.sponza_scale(n_side=48, aspect=W / H)              # beyond LDS: the traversal copy is read from memory by all three
+    scene.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    settings = [S.graphics_settings(W, H, spp=2, bounces=5, frame_index=f) for f in range(3)]
+    alone = [gpu_render(ptamd, gpu, scene, gs, W, H)[0]["Radiance"] for gs in settings]
+    lanes = []
+    for k in range(3):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx = ptamd.DeviceContext(0, stream=stream.cuda_stream)
+            ctx.set_sharding(0, 1, 16)
+            sc = ptamd.Scene(ctx, scene) if k == 0 else ptamd.SharedScene(ctx, lanes[0][2])
+            lanes.append((stream, ctx, sc, ptamd.Renderer(ctx, sc, W, H)))
+        stream.synchronize()
+    try:
+        own, view = lanes[0][1].accel_stats(), lanes[1][1].accel_stats()
+        assert own.SharedScene == 0 and own.BlobBytes > 0 and view.SharedScene == 1 and view.BlobBytes == 0
+        assert view.InstanceCount == own.InstanceCount
+        for it in range(3):
+            for k, (stream, ctx, sc, r) in enumerate(lanes):
+                with torch.cuda.stream(stream):
+                    r.render(settings[(k + it) % 3])
+            torch.cuda.synchronize()
+            for k, (stream, ctx, sc, r) in enumerate(lanes):
+                assert np.array_equal(ptamd.textures_to_numpy(r.textures)["Radiance"], alone[(k + it) % 3]), (it, k)
+        owner = lanes[0][1]
+        with pytest.raises(ptamd.PtInvalidArgument, match="view this context"):
+            owner.check(owner.lib.pt_release_bottom_level(owner.handle, lanes[0][2].blas_ids[0]))
+        with pytest.raises(ptamd.PtInvalidArgument, match="view this context"):
+            lanes[0][2]._build_top_level()
+    finally:
+        for stream, ctx, sc, r in reversed(lanes):                # views first, then the owner
+            ctx.close()
+
+
+def test_release_of_a_referenced_bottom_level_drops_the_top_level(ptamd, pkg):
+    """pt_release_bottom_level used to free arrays the live TLAS still pointed at. Now the TLAS dies with it and a render
+    answers PT_ERROR_NOT_READY (status -4) until the next pt_build_top_level."""
+    S = pkg.scenes
+    W, H = 64, 36
+    ctx = ptamd.DeviceContext(0)
+    try:
+        scene = S.cornell_box(aspect=W / H)
+        g = ptamd.Scene(ctx, scene)
+        r = ptamd.Renderer(ctx, g, W, H)
+        gs = S.graphics_settings(W, H, spp=1, bounces=2)
+        r.render(gs); ctx.sync()
+        ctx.check(ctx.lib.pt_release_bottom_level(ctx.handle, g.blas_ids[6]))
+        with pytest.raises(ptamd.PtError, match="status -4"):
+            r.render(gs)
+        # an unreferenced bottom level can go without touching the TLAS
+        g2 = ptamd.Scene(ctx, scene)                              # builds its own BLASes and a new TLAS
+        r2 = ptamd.Renderer(ctx, g2, W, H)
+        for bid in g.blas_ids[:6] + g.blas_ids[7:]:
+            ctx.check(ctx.lib.pt_release_bottom_level(ctx.handle, bid))
+        g.blas_ids = []
+        r2.render(gs); ctx.sync()
+    finally:
+        ctx.close()
+
+
+def test_scene_inputs_are_validated(ptamd, pkg):
+    """indices the kernels dereference are checked once per scene change, with a message naming the culprit."""
+    import torch
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 64, 36
+    gs = S.graphics_settings(W, H, spp=1, bounces=2)
+
+    def render_with(mutate, match):
+        ctx = ptamd.DeviceContext(0)
+        try:
+            scene = S.cornell_box_textured(aspect=W / H, env=None)
+            g = ptamd.Scene(ctx, scene)
+            od = scene.object_data.copy()
+            n = mutate(od, len(scene.heap))
+            dev = ptamd.to_device(od[:n] if n else od, g.device)
+            ctx.check(ctx.lib.pt_set_object_data(ctx.handle, dev.data_ptr(), n if n else len(od)))
+            r = ptamd.Renderer(ctx, g, W, H)
+            with pytest.raises(ptamd.PtInvalidArgument, match=match):
+                r.render(gs)
+        finally:
+            ctx.close()
+
+    def bad_vertices(od, heap_count):
+        od["MeshDescriptors"]["Vertices"][3] = heap_count + 5
+
+    def texture_as_index_buffer(od, heap_count):
+        tex = [int(d) for d in od["TextureMapInfoArray"]["Descriptor"].reshape(-1) if d != 0xFFFFFFFF][0]
+        od["MeshDescriptors"]["Indices"][2] = tex
+
+    def bad_texture(od, heap_count):
+        od["TextureMapInfoArray"]["Descriptor"][1][0] = heap_count
+
+    def too_few_objects(od, heap_count):
+        return len(od) - 1
+
+    render_with(bad_vertices, r"ObjectData\[3\]\.MeshDescriptors\.Vertices = \d+ is beyond the descriptor heap")
+    render_with(texture_as_index_buffer, r"ObjectData\[2\]\.MeshDescriptors\.Indices = \d+ is not the kind")
+    render_with(bad_texture, r"ObjectData\[1\]\.TextureMapInfo\.Descriptor = \d+ is beyond")
+    render_with(too_few_objects, r"only \d+ objects are bound")

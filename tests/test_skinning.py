@@ -71,3 +71,35 @@ def test_gpu_skinning_update_and_motion_vectors(gpu, ptamd, oracle, pkg):
             mv = out["MotionVector"].view(np.float16)[..., :2].astype(np.float32)
             assert np.abs(mv).max() > 1.0
     assert np.array_equal(prev, scene.instance_data["ObjectToWorld"])
+
+
+@pytest.mark.gpu
+def test_update_keeps_the_opaque_flag_of_alpha_tested_geometry(gpu, ptamd, oracle, pkg):
+    """the PERFORM_UPDATE path recomputes D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE from AlphaMode like the build does
+    (Scene.ixx:320-324). A blend-mode skinned column must still let rays through after an update: compared with the oracle."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 96, 54
+    scene = S.dynamic_scene(aspect=W / H)
+    bar = scene.nodes[2].meshes[0]
+    bar.material["AlphaMode"] = 2                                # Blend
+    bar.material["BaseColor"] = (0.8, 0.5, 0.2, 0.25)            # alpha below 0.5: IsOpaque rejects every candidate
+    scene.finalize()
+    gpu.set_sharding(0, 1, 16)
+    g = ptamd.Scene(gpu, scene)
+    r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
+    pose = S.bar_pose(30.0, 0.1)
+    g.SkinSkeletalMeshes(bar, pose); oracle_skin(oracle, bar, pose); gpu.sync()
+    g.UpdateAccelerationStructures(2)
+    gs = S.graphics_settings(W, H, spp=2, bounces=4, frame_index=1)
+    for t in r.textures.values():
+        t.zero_()
+    gpu.reset_counters(); r.render(gs); gpu.sync()
+    out = ptamd.textures_to_numpy(r.textures); c = gpu.counters()
+    ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+    assert np.array_equal(out["Position"].view(np.uint32), ref_gb["Position"].view(np.uint32))
+    assert c.PrimaryRays + c.SecondaryRays == ref_rays
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+    # the column is invisible to primary rays: no pixel's position lies on it (x within the column's 0.24 footprint around its instance)
+    opaque = S.dynamic_scene(aspect=W / H); opaque.finalize()
+    ref_opaque, _, _ = oracle.render(opaque, gs, accel_mode=0, layouts=L)
+    assert not np.array_equal(ref_opaque["Position"], ref_gb["Position"])
