@@ -82,6 +82,7 @@ void pt_destroy(PtContext* ctx)
     if (c.frameConstants) hipFree(c.frameConstants);
     if (c.pixelAux) hipFree(c.pixelAux);
     if (c.queueCounts) hipFree(c.queueCounts);
+    if (c.roundArgs) hipFree(c.roundArgs);
     if (c.counters) hipFree(c.counters);
     for (auto e : c.evExtend) hipEventDestroy(e);
     for (auto e : c.evRound) hipEventDestroy(e);

@@ -84,6 +84,7 @@ struct PathQueue {
 };
 
 struct FrameConstants { PtCamera cam; PtSceneData sd; PtGraphicsSettings gs; };
+struct RoundArgs;
 
 struct DeviceCounters {
     unsigned long long primaryRays, secondaryRays, nodesVisited, trianglesTested;
@@ -128,6 +129,7 @@ struct Context {
     FrameConstants* frameConstants = nullptr;
     hipGraphExec_t graphExec = nullptr; std::string graphKey; bool disableGraphs = false;
     uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;
+    struct RoundArgs* roundArgs = nullptr; uint32_t roundArgsCap = 0; std::string roundArgsKey;   // per-round argument blocks of k_round (device)
     DeviceCounters* counters = nullptr;
     uint64_t lastIterations = 0;
     uint32_t debugFlags = 0;

@@ -13,6 +13,8 @@
 // MFMA is not used: there is no dense contraction on this path.
 #include "pt_internal.hpp"
 
+#include <cstring>
+
 namespace pt {
 
 // ---------------------------------------------------------------------------------------------
@@ -724,11 +726,21 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
 // rounds, 1/8-frame shards of the multi-GPU run) are made of.
 // 4 waves per SIMD = 128 VGPRs: fits without a spill (csrc/Makefile: -fno-slp-vectorize) and matches the 4 blocks per CU
 // the LDS footprint allows.
+// Everything a round needs, in device memory: the kernel takes ONE pointer. By-value kernel arguments are all loaded into SGPRs at
+// kernel entry and stay live to their last use -- ~100 scalar registers for these structs, 60-70 of them spilled to VGPR lanes
+// (v_writelane / v_readlane on the VALU pipe the kernel is bound by). Behind a pointer each field is an s_load where it is used.
+struct RoundArgs {
+    SceneView sv; FrameView fv; PtTextures tx; BlobView bv; PathQueue qin, qout;
+    const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap, _pad;
+};
+
 template <bool TEXTURED, bool LDS, bool FLAT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, BlobView bv,
-                                               PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
-                                               DeviceCounters* counters)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(const RoundArgs* __restrict__ A)
 {
+    const SceneView& sv = A->sv; const FrameView& fv = A->fv; const PtTextures& tx = A->tx; const BlobView& bv = A->bv;
+    const PathQueue& qin = A->qin; const PathQueue& qout = A->qout;
+    const FrameConstants* __restrict__ fc = A->fc; float2* aux = A->aux; const uint32_t segCap = A->segCap;
+    const uint32_t* countIn = A->countIn; uint32_t* countOut = A->countOut; DeviceCounters* counters = A->counters;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t lds[16];
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
@@ -1198,7 +1210,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
                 uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
                 timing_begin(c, c.evRound, c.nRound);
-                #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(sv, fv, c.frameConstants, tx, c.blob, qin, qout, aux, segCap, cin, cout, c.counters)
+                #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(c.roundArgs + r)
                 #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)
                 #define PT_ROUND_L(T) do { if (lds) PT_ROUND_F(T, true); else PT_ROUND_F(T, false); } while (0)
                 if (c.heapHasTextures) PT_ROUND_L(true); else PT_ROUND_L(false);
@@ -1272,14 +1284,36 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     const uint32_t grid = std::min(persistent_grid(c.device), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
     c.lastIterations = rounds + 1;
 
+    // everything the launch sequence depends on: the key of the per-round argument blocks and of the captured graph
+    std::string key;
+    key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
+    key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
+    key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
+    if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
+        if (rounds + 1 > c.roundArgsCap) {
+            if (c.roundArgs) hipFree(c.roundArgs);
+            c.roundArgs = nullptr; c.roundArgsCap = 0;
+            if ((e = hipMalloc((void**)&c.roundArgs, sizeof(RoundArgs) * (rounds + 1))) != hipSuccess) return e;
+            c.roundArgsCap = rounds + 1;
+        }
+        std::vector<RoundArgs> host(rounds + 1);
+        float2* aux = gs.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
+        for (uint32_t r = 0; r <= rounds; r++) {
+            RoundArgs& a = host[r];
+            std::memset(&a, 0, sizeof a);
+            a.sv = sv; a.fv = fv; a.tx = tx; a.bv = c.blob; a.qin = c.queue[r & 1]; a.qout = c.queue[(r + 1) & 1];
+            a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * kCountStride]; a.countOut = &c.queueCounts[(r + 1) * kCountStride];
+            a.counters = c.counters; a.segCap = segCap;
+        }
+        if ((e = hipMemcpyAsync(c.roundArgs, host.data(), sizeof(RoundArgs) * (rounds + 1), hipMemcpyHostToDevice, c.stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(c.stream)) != hipSuccess) return e;    // once per change of the scene / frame geometry, never per frame
+        c.roundArgsKey = key;
+    }
+
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
     const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
                            (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP)) == 0;   // counters / validation variants launch directly
     if (graphable) {
-        std::string key;
-        key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
-        key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
-        key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
         if (key != c.graphKey || !c.graphExec) {
             if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }
             c.graphKey.clear();
