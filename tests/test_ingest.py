@@ -112,3 +112,59 @@ def test_gpu_matches_oracle_on_ingested_scene(ingest, pkg, oracle, gpu, ptamd, t
     assert c.PrimaryRays + c.SecondaryRays == ref_rays
     assert np.array_equal(out["Position"].view(np.uint32), ref_gb["Position"].view(np.uint32))
     assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+
+
+def test_hand_written_fixture_matches_hand_derived_arrays(pkg):
+    """an ingest check with no exporter in the loop. tests/golden/ingest/{fixture.gltf,scene.json} are written by
+    tests/golden/make_ingest_fixture.py with struct + json only; every expected array below is derived BY HAND from the reference:
+
+      indices   GLTFHelpers.ixx:179   slot count-1-i <- index i (order AND winding reversed); :183-188 R16_UINT iff count <= 65535,
+                                      whatever the component type in the file (the 3-index triangle is UNSIGNED_INT there)
+      vertices  positions as they are (the Z flip lives in the instance transform), normals SNORM16 (Vertex.ixx:17-22)
+      instances Scene.ixx:199-214     world = GlobalTransform * Scale(1,1,-1) * (Scale * Rotation * Translation), row vectors; for a point
+                                      (x, y, z) of the quad under RenderObject "a":  node chain (1,2,3)+2*RotY90 -> (2z+1, 2y+2, -2x+3),
+                                      Z flip -> (2z+1, 2y+2, 2x-3), Yaw 90 (x' = z, z' = -x) -> (2x-3, 2y+2, -2z-1), +(10,0,0) -> (2x+7, 2y+2, -2z-1)
+      rotations JSONConverters.ixx:18-26: {Yaw,Pitch,Roll} non-zero -> CreateFromYawPitchRoll(yaw, -pitch, -roll); all zero -> raw quaternion
+                                      ((0,0,sin45,cos45) = 90 degrees about Z: (x, y, z) -> (-y, x, z))
+    """
+    import dxpbrt_amd.ingest as I
+    import os
+    L = pkg.layouts
+    sc = I.load_scene(os.path.join(os.path.dirname(__file__), "golden", "ingest", "scene.json"), aspect=1.0)
+    assert len(sc.nodes) == 2 and len(sc.objects) == 4
+    quad, tri = sc.nodes[0].meshes[0], sc.nodes[1].meshes[0]
+    # ---- index buffers
+    assert quad.indices.dtype == np.uint16 and quad.indices.tolist() == [3, 2, 0, 2, 1, 0]
+    assert tri.indices.dtype == np.uint16 and tri.indices.tolist() == [2, 1, 0]
+    # ---- vertices
+    assert quad.vertices["Position"].tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]
+    assert quad.vertices["Normal"].tolist() == [[0, 0, 32767]] * 4 and quad.has_normals and not quad.has_tangents
+    assert tri.vertices["Position"].tolist() == [[0, 0, 0], [2, 0, 0], [0, 0, 2]] and not tri.has_normals
+    # ---- materials (GLTFHelpers.ixx:330-368; no material -> Material() defaults, App.cpp:1044)
+    m = quad.material
+    assert np.allclose(m["BaseColor"], (0.8, 0.2, 0.1, 1.0)) and float(m["EmissiveStrength"]) == 3.0 and np.allclose(m["EmissiveColor"], (1.0, 0.5, 0.25))
+    assert float(m["Metallic"]) == 0.25 and float(m["Roughness"]) == 0.5 and np.isclose(float(m["IOR"]), 1.33) and float(m["Transmission"]) == 0.75
+    assert int(m["AlphaMode"]) == 1 and np.isclose(float(m["AlphaCutoff"]), 0.3)
+    assert tri.material is None
+    od = sc.object_data
+    assert np.allclose(od["Material"]["BaseColor"][1], (0, 0, 0, 1)) and float(od["Material"]["IOR"][1]) == 1.5 and float(od["Material"]["Roughness"][1]) == 0.5
+    assert int(od["VertexDesc"]["Stride"][0]) == 32 and int(od["VertexDesc"]["Normal"][0]) == 12
+    assert int(od["VertexDesc"]["Normal"][1]) == 0xFFFFFFFF and int(od["VertexDesc"]["Tangent"][0]) == 0xFFFFFFFF
+    # ---- instances: order (render object major, mesh nodes in scene order), ids, masks, transforms
+    assert sc.instance_data["FirstGeometryIndex"].tolist() == [0, 1, 2, 3] and list(sc.instance_ids) == [0, 1, 2, 3]
+    assert list(sc.instance_masks) == [255, 255, 0, 0] and list(sc.instance_blas) == [0, 1, 0, 1]
+    expect = np.array([
+        [[2, 0, 0, 7], [0, 2, 0, 2], [0, 0, -2, -1]],            # a / quad : (2x+7, 2y+2, -2z-1)
+        [[0, 0, -1, 9.5], [0, 1, 0, 0], [-1, 0, 0, 1]],          # a / tri  : (9.5-z, y, 1-x)
+        [[0, -2, 0, -2], [0, 0, 2, 6], [2, 0, 0, -3]],           # b / quad : (-2y-2, 2z+6, 2x-3)
+        [[0, -1, 0, 0], [1, 0, 0, 4], [0, 0, -1, -0.5]],         # b / tri  : (-y, x+4, -z-0.5)
+    ], np.float32)
+    got = sc.instance_data["ObjectToWorld"].reshape(4, 3, 4)
+    assert np.allclose(got, expect, atol=1e-6), got
+    assert np.allclose(sc.instance_data["PreviousObjectToWorld"].reshape(4, 3, 4), expect, atol=1e-6)
+    # ---- camera (Yaw 90: forward (0,0,1) -> (1,0,0), right (1,0,0) -> (0,0,-1)) and environment
+    cam = sc.camera
+    assert np.allclose(cam["Position"], (0, 1, -5)) and np.allclose(cam["ForwardDirection"], (1, 0, 0), atol=1e-6)
+    assert np.allclose(cam["RightDirection"] / np.linalg.norm(cam["RightDirection"]), (0, 0, -1), atol=1e-6)
+    assert np.allclose(cam["UpDirection"] / np.linalg.norm(cam["UpDirection"]), (0, 1, 0), atol=1e-6)
+    assert np.allclose(sc.scene_data["EnvironmentLightColor"], (0.1, 0.2, 0.3, 1.0))
