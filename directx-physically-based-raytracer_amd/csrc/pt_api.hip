@@ -397,8 +397,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;
-    c.tlasObjectEnd = objectEnd;
-    c.validated = false;
+    if (objectEnd != c.tlasObjectEnd || count != c.tlasValidatedCount) c.validated = false;     // same instances over the same objects: nothing new to check
+    c.tlasObjectEnd = objectEnd; c.tlasValidatedCount = count;
     c.haveTlas = true;
     return PT_OK;
 }

@@ -112,6 +112,7 @@ struct Context {
     WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check
     uint32_t maxBlasDepth = 0, tlasInstanceCap = 0;
     size_t blobCapacity = 0;
+    uint32_t tlasValidatedCount = ~0u, persistentGrid = 0;
     uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
     bool validated = false; uint32_t* validateDev = nullptr;   // descriptor / index validation of the scene inputs (pt_api.hip make_views)
     const void* validatedObjects = nullptr; uint32_t validatedObjectCount = 0;

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, Pa
     if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
 }
 
-static uint32_t persistent_grid(int device);
+static uint32_t persistent_grid(Context& c);
 
 // batch entry points for direct-lighting style consumers (RTXDI bridge shape), see include/ptamd.h
 __global__ __launch_bounds__(256) void k_visibility(BlobView bv, AlphaContext ac, const float4* __restrict__ rays, uint32_t count, float4* __restrict__ out,
@@ -1088,7 +1088,7 @@ hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, 
 {
     if (!count) return hipSuccess;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
-    k_visibility<<<persistent_grid(c.device), 256, 0, c.stream>>>(c.blob, ac, (const float4*)rays, count, (float4*)out, c.counters);
+    k_visibility<<<persistent_grid(c), 256, 0, c.stream>>>(c.blob, ac, (const float4*)rays, count, (float4*)out, c.counters);
     return hipGetLastError();
 }
 
@@ -1118,11 +1118,14 @@ __global__ void k_deinterleave(uint8_t* dst, const uint8_t* src, RankOffsets ran
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-static uint32_t persistent_grid(int device)
+static uint32_t persistent_grid(Context& c)
 {
-    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
-    const uint32_t g = (uint32_t)p.multiProcessorCount * 8u;      // 1536..4096 blocks perform alike on C2; far fewer or more lose
-    return (g + kSubQueues - 1) / kSubQueues * kSubQueues;          // whole number of blocks per sub-queue
+    if (!c.persistentGrid) {                                        // asked once: hipGetDeviceProperties is a slow host call
+        hipDeviceProp_t p;
+        const uint32_t g = hipGetDeviceProperties(&p, c.device) == hipSuccess ? (uint32_t)p.multiProcessorCount * 8u : 1024u;   // 1536..4096 blocks perform alike on C2
+        c.persistentGrid = (g + kSubQueues - 1) / kSubQueues * kSubQueues;                                                        // whole number of blocks per sub-queue
+    }
+    return c.persistentGrid;
 }
 
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx)
@@ -1281,7 +1284,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * kCountStride);
     // persistent grid, but never more blocks than the queue has tiles: surplus blocks only cost dispatch slots and LDS that
     // a concurrent frame's kernels (other streams) could use -- this matters for small shards (1/8 of a 1080p frame = 1013 tiles)
-    const uint32_t grid = std::min(persistent_grid(c.device), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
+    const uint32_t grid = std::min(persistent_grid(c), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
     c.lastIterations = rounds + 1;
 
     // everything the launch sequence depends on: the key of the per-round argument blocks and of the captured graph

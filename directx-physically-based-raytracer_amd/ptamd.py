@@ -314,11 +314,15 @@ class Scene:
         ctx, lib = self.ctx, self.ctx.lib
         hv = next(h for m, h, _ in self.desc.geometry if m is mesh)
         hm = int(self.desc._motion_heap[id(mesh)])
-        if id(mesh) not in self._skin_cache:
-            self._skin_cache[id(mesh)] = to_device(mesh.skeletal_vertices, self.device)
-        tr = to_device(np.ascontiguousarray(skeletal_transforms, np.float32), self.device)
-        self._buffers.append(tr)
-        ctx.check(lib.pt_skin_mesh(ctx.handle, C.c_void_p(self._skin_cache[id(mesh)].data_ptr()), C.c_void_p(tr.data_ptr()),
+        torch = _torch()
+        if id(mesh) not in self._skin_cache:                     # skeletal vertices once; joint matrices: a pinned staging tensor + a device
+            n = int(np.asarray(skeletal_transforms).size)         # tensor that live as long as the scene (no allocation, no wait per frame)
+            self._skin_cache[id(mesh)] = (to_device(mesh.skeletal_vertices, self.device), torch.zeros(n, dtype=torch.float32).pin_memory(),
+                                          torch.zeros(n, dtype=torch.float32, device=self.device))
+        sk, staging, tr = self._skin_cache[id(mesh)]
+        staging.copy_(torch.from_numpy(np.ascontiguousarray(skeletal_transforms, np.float32).reshape(-1)))
+        tr.copy_(staging, non_blocking=True)
+        ctx.check(lib.pt_skin_mesh(ctx.handle, C.c_void_p(sk.data_ptr()), C.c_void_p(tr.data_ptr()),
                                    C.c_void_p(self._heap_dev[hv].data_ptr()), C.c_void_p(self._heap_dev[hm].data_ptr()), len(mesh.vertices)))
 
     def UpdateAccelerationStructures(self, node_index):
