@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""gpurun_out/final/* -> profiles/r02_* and profiles/traffic.json (HBM bytes per launch and VALU instructions per frame from the PMC
+summaries, stamped with the hash of the kernel sources they were measured on: bench.py only quotes them for the same sources)."""
+import json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SRC = os.path.join(ROOT, "gpurun_out", "final"); DST = os.path.join(ROOT, "profiles")
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec)
+sys.argv = ["bench.py"]; spec.loader.exec_module(bench)
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line.strip(); out[cur] = {}
+        else:
+            p = line.split()
+            out[cur][p[0]] = (float(p[1]), int(p[3]))
+    return out
+
+KERNEL_KEY = {"k_round": "k_round", "k_extend_stream": "k_extend", "k_extend2": "k_extend", "k_shade": "k_shade"}
+traffic = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (KB), "
+                   "divided by the dispatch count, for the variant of each kernel the workload runs; valu: SQ_INSTS_VALU of all kernels of one frame. "
+                   "Sources: profiles/r02_<workload>_pmc_summary.txt. source_hash = bench.source_hash() of the kernel sources measured."}
+for w in ("c2", "c3", "c5"):
+    for f in os.listdir(SRC):
+        if f.startswith(w + "_") and os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err"):
+            shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
+    pm = parse(os.path.join(SRC, w + "_pmc_summary.txt"))
+    frames = None; ent = {"source_hash": bench.source_hash()}
+    valu_total = 0.0
+    for k, c in pm.items():
+        if "SQ_INSTS_VALU" not in c: continue
+        name = k.replace("pt::", "").split("<")[0]
+        stats_variant = re.search(r"<true", k) and name in ("k_extend2", "k_extend_stream", "k_gbuffer")
+        if name == "k_gbuffer" and not stats_variant:
+            frames = c["SQ_INSTS_VALU"][1]                      # one G-buffer launch per frame
+    for k, c in pm.items():
+        if "SQ_INSTS_VALU" not in c: continue
+        name = k.replace("pt::", "").split("<")[0]
+        if re.search(r"k_(extend2|extend_stream|gbuffer)<true", k): continue      # the statistics variants run once, outside the frames
+        valu_total += c["SQ_INSTS_VALU"][0]
+        if name in KERNEL_KEY and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            ent[KERNEL_KEY[name]] = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0 / c["FETCH_SIZE"][1]
+    if frames:
+        ent["valu"] = {"wave_instructions_per_frame": valu_total / frames, "frames_in_profile": frames}
+    traffic[w] = ent
+for f in ("dynamic_bench.json", "c2_rehearse_collective.json"):
+    if os.path.exists(os.path.join(SRC, f)): shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
+json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
