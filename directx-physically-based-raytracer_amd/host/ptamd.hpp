@@ -44,6 +44,11 @@ struct CommandList {
     ~CommandList() { pt_destroy(Context); }
 
     void End() { ThrowIfFailed(Context, pt_sync(Context)); }            // CommandList::End + Wait, Source/CommandList.ixx:86-119
+
+    // Frames in flight: this command list renders the scene `owner` built (acceleration structures, descriptor table, object and
+    // instance data), read-only, on its own stream with its own path queues. The reference has ONE Scene whatever the number of
+    // frames in flight (Source/App.cpp:372-374). `owner` must outlive the sharing.
+    void ShareScene(const CommandList& owner) { ThrowIfFailed(Context, pt_share_scene(Context, owner.Context)); }
 };
 
 // GPUBuffer* / Texture* slots of the reference become plain device pointers here.

@@ -28,23 +28,21 @@ for w in ("c2", "c3", "c5"):
         if f.startswith(w + "_") and os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err"):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
     pm = parse(os.path.join(SRC, w + "_pmc_summary.txt"))
-    frames = None; ent = {"source_hash": bench.source_hash()}
+    ent = {"source_hash": bench.source_hash()}
+    # the kernels of the product path of this workload (the statistics frame of bench.py runs other variants: not counted)
+    product = ("k_round<false", "k_gbuffer<false", "k_pt_init", "k_set_constants") if w == "c2" else \
+              ("k_shade<false", "k_extend_stream<false", "k_gbuffer<false", "k_pt_init", "k_set_constants")
+    frames = max(c["SQ_INSTS_VALU"][1] for k, c in pm.items() if "k_gbuffer<false" in k and "SQ_INSTS_VALU" in c)   # one G-buffer launch per frame
     valu_total = 0.0
     for k, c in pm.items():
-        if "SQ_INSTS_VALU" not in c: continue
-        name = k.replace("pt::", "").split("<")[0]
-        stats_variant = re.search(r"<true", k) and name in ("k_extend2", "k_extend_stream", "k_gbuffer")
-        if name == "k_gbuffer" and not stats_variant:
-            frames = c["SQ_INSTS_VALU"][1]                      # one G-buffer launch per frame
-    for k, c in pm.items():
-        if "SQ_INSTS_VALU" not in c: continue
-        name = k.replace("pt::", "").split("<")[0]
-        if re.search(r"k_(extend2|extend_stream|gbuffer)<true", k): continue      # the statistics variants run once, outside the frames
+        name = k.replace("pt::", "")
+        if "SQ_INSTS_VALU" not in c or not name.startswith(product): continue
         valu_total += c["SQ_INSTS_VALU"][0]
-        if name in KERNEL_KEY and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            ent[KERNEL_KEY[name]] = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0 / c["FETCH_SIZE"][1]
-    if frames:
-        ent["valu"] = {"wave_instructions_per_frame": valu_total / frames, "frames_in_profile": frames}
+        base = name.split("<")[0]
+        if base in KERNEL_KEY and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            ent[KERNEL_KEY[base]] = (2.0 * c["FETCH_SIZE"][0] + c["WRITE_SIZE"][0]) * 1024.0 / c["FETCH_SIZE"][1]
+    ent["valu"] = {"wave_instructions_per_frame": valu_total / frames, "frames_in_profile": frames,
+                   "note": "k_gbuffer dispatches = frames; for c3 / c5 one of them is bench.py's statistics frame, whose k_shade launches are included (one frame in %d)" % frames}
     traffic[w] = ent
 for f in ("dynamic_bench.json", "c2_rehearse_collective.json"):
     if os.path.exists(os.path.join(SRC, f)): shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
