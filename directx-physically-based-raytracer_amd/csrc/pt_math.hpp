@@ -420,7 +420,9 @@ struct BSDFSample {                           // BxDF.hlsli:36-44
     }
 };
 
-// ---- Shaders/SelfIntersectionAvoidance.hlsli:39-117 (NVIDIA, BSD-3; restated) ---------------
+// ---- Shaders/SelfIntersectionAvoidance.hlsli:39-117, restated --------------------------------
+// Method, operation order and error-bound constants: "Solving Self-Intersection Artifacts in DirectX Raytracing",
+// Copyright (c) 2023 NVIDIA CORPORATION & AFFILIATES, BSD-3-Clause -- full notice in THIRD_PARTY_NOTICES.md at the repository root.
 // M = objectToWorld 3x4, W = worldToObject 3x4 (row-major).
 PT_DEV void safe_triangle_spawn_point(v3 v0, v3 v1, v3 v2, float bx, float by, const float* M, const float* W,
                                       v3& objPosition, v3& wldPosition, v3& wldNormal, float& wldOffsetOut)

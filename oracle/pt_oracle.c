@@ -548,6 +548,7 @@ int or_bsdf_sample(const float mat[7], int front_face, const float Ng[3], const 
 
 /* ======================================================================== */
 /* SelfIntersectionAvoidance.hlsli:39-117, HitInfo.hlsli                     */
+/* method and constants: Copyright (c) 2023 NVIDIA CORPORATION & AFFILIATES, BSD-3-Clause (THIRD_PARTY_NOTICES.md) */
 /* ======================================================================== */
 void or_safe_spawn(const float v[9], const float bary[2], const float M[12], const float W[12],
                    float objPosOut[3], float wldPosOut[3], float objNOut[3], float wldNOut[3], float* offset)
