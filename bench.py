@@ -204,6 +204,7 @@ def main():
             with torch.cuda.stream(self.stream):
                 self.ctx = P.DeviceContext(local_rank, stream=self.stream.cuda_stream)
                 self.ctx.set_sharding(rank, args.emulate_world if args.emulate_world else world, BAND)
+                self.ctx.set_frames_in_flight(max(1, args.inflight))
                 self.scene = P.Scene(self.ctx, scene, device) if owner is None else P.SharedScene(self.ctx, owner.scene)
                 self.renderer = P.Renderer(self.ctx, self.scene, W, H)
                 if collective:                                  # equal-sized gather pieces
@@ -306,6 +307,8 @@ def main():
     # ---- roofline (N = 1). Everything below runs AFTER the timed region, on lane 0 alone.
     instrumented = world == 1 and not collective and not args.emulate_world and not args.no_kernel_timing and not dynamic
     if rank == 0 and instrumented:
+        ctx.set_frames_in_flight(1)                              # from here on lane 0 has the GPU to itself
+
         def frames_on_lane0(n, first):
             with torch.cuda.stream(lanes[0].stream):
                 for i in range(n):

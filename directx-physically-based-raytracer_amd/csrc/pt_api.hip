@@ -99,6 +99,15 @@ int pt_set_stream(PtContext* ctx, void* hip_stream)
     return PT_OK;
 }
 
+int pt_set_frames_in_flight(PtContext* ctx, uint32_t frames)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    API_ARG(&ctx->c, frames >= 1, "frames in flight must be at least 1");
+    ctx->c.framesInFlight = frames;
+    ctx->c.graphKey.clear();                              // the launch geometry of the captured frame depends on it
+    return PT_OK;
+}
+
 int pt_sync(PtContext* ctx)
 {
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;

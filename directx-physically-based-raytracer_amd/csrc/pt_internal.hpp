@@ -107,6 +107,7 @@ struct Context {
     Tlas tlas; bool haveTlas = false;
     Context* sceneOwner = nullptr;                    // pt_share_scene: tlas / blob below are views of that context's, never freed here
     int borrowers = 0;                                // contexts viewing THIS context's scene
+    uint32_t framesInFlight = 1;                      // pt_set_frames_in_flight: how many contexts render concurrently on this GPU (grid sizing)
     std::vector<uint64_t> tlasBlasIds;                // bottom levels the live TLAS refers to (pt_release_bottom_level checks)
     std::vector<uint8_t> tlasUploadHost; void* tlasUploadDev = nullptr; size_t tlasUploadCap = 0;   // InstanceSource | BlasEntry | BlobCopy
     WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check

@@ -1199,7 +1199,12 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 timing_end(c, c.evShade, c.nShade); c.nShade++;
                 if (r == rounds) break;
                 timing_begin(c, c.evExtend, c.nExtend);
-                #define PT_XS(S, W) k_extend_stream<S, W><<<grid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
+                // Fewer, longer-lived waves than the other kernels: a wave only keeps its lanes busy if it refills them many times, and with
+                // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
+                // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
+                // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
+                const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? 512u : 1024u));
+                #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
                 if (stats) { if (wt) PT_XS(true, true); else PT_XS(true, false); } else { if (wt) PT_XS(false, true); else PT_XS(false, false); }
                 #undef PT_XS
                 timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
@@ -1292,6 +1297,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
     key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
     key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
+    key_add(key, c.framesInFlight);
     if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
         if (rounds + 1 > c.roundArgsCap) {
             if (c.roundArgs) hipFree(c.roundArgs);

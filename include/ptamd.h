@@ -167,6 +167,10 @@ const char* pt_last_error(const PtContext* ctx);            /* ctx may be NULL: 
 /* hipStream_t to enqueue on (NULL = the default stream). Reference: CommandList recording order. */
 int  pt_set_stream(PtContext* ctx, void* hip_stream);
 int  pt_sync(PtContext* ctx);                               /* reference: CommandList::End/Wait, Source/CommandList.ixx:86-119 */
+/* How many contexts render concurrently on this GPU (frames in flight on separate streams; reference: the swap chain's
+ * back-buffer count, Source/DeviceResources.cpp). A performance hint only -- it sizes the persistent grids: a kernel that shares
+ * the GPU with other frames' kernels launches fewer, longer-lived workgroups. Default 1. */
+int  pt_set_frames_in_flight(PtContext* ctx, uint32_t frames);
 
 /* ------------------------------------------------------------------------------------------
  * descriptor heap analogue. ObjectData.MeshDescriptors.{Vertices,Indices} index this table

@@ -19,6 +19,7 @@ def child(lib, workload, frames, inflight):
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             ctx = P.DeviceContext(0, stream=st.cuda_stream)
+            if hasattr(ctx, 'set_frames_in_flight'): ctx.set_frames_in_flight(inflight)
             g = P.Scene(ctx, scene)
             lanes.append((st, ctx, g, P.Renderer(ctx, g, W, H)))
     def frame(i):
