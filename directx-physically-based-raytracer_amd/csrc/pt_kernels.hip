@@ -859,8 +859,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     bool exhausted = false;                                  // wave-uniform
     const bool oneInstance = bv.instCount == 1u;
     uint32_t rayNodes = 0;
+#ifdef PT_STREAM_PROF
+    uint32_t prof[13] = { 0 };
+#endif
     while (true) {
         const unsigned long long busy = __ballot(qi != ~0u);
+#ifdef PT_STREAM_PROF
+        prof[12]++;
+#endif
         if (exhausted && !busy) break;
         {
             const unsigned long long idle = ~busy;
@@ -870,6 +876,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 if (lane == 0) base = atomicAdd(&cursor[sq], nIdle);
                 base = (uint32_t)__shfl((int)base, 0);
                 if (base + nIdle >= nT) exhausted = true;
+#ifdef PT_STREAM_PROF
+                prof[10]++; prof[11] += base < nT ? min(nIdle, nT - base) : 0u;
+#endif
                 if (qi == ~0u) {
                     const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
                     if (e < nT) {
@@ -898,6 +907,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             const uint32_t most = max(nNode, max(nTri, nEnter));
             const uint32_t lim = max(kStreamMinLanes, most >> kStreamShareShift);
             const bool doNode = nNode >= lim || nNode == most, doTri = nTri >= lim || nTri == most, doEnter = nEnter >= lim || nEnter == most;
+#ifdef PT_STREAM_PROF
+            {
+                const uint32_t nLive = (uint32_t)__popcll(__ballot(live));
+                prof[0]++; prof[7] += nLive;
+                if (doNode && nNode) { prof[1]++; prof[2] += nNode; }
+                if (doTri && nTri) { prof[3]++; prof[4] += nTri; }
+                if (doEnter && nEnter) { prof[5]++; prof[6] += nEnter; }
+                if (exhausted) { prof[8]++; prof[9] += nLive; }
+            }
+#endif
             // what this lane does: 0 nothing, 1 node, 2 triangle, 4 instance entry
             uint32_t act = 0, addr = 0, item = 0;
             if (leaf && (top ? doEnter : doTri)) {
@@ -973,6 +992,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     }
     if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
     if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
+#ifdef PT_STREAM_PROF
+    // developer build only (tools/stream_prof.py): per-wave tallies of section executions and the lanes in them, through the mismatch record
+    if (lane == 0) for (int i = 0; i < 13; i++) atomicAdd((unsigned int*)&counters->mismatchRay[i], prof[i]);
+#endif
 }
 
 template <bool STATS>

@@ -287,6 +287,60 @@ def test_edge_case_scenes_bit_identical_to_oracle(gpu, ptamd, oracle, pkg):
     check(many)
 
 
+def test_pathological_mesh_coincident_centroids_and_diagonal_slivers(gpu, ptamd, oracle, pkg):
+    """What a Morton-ordered builder likes least: thousands of triangles whose centroids coincide (one Morton cell: the
+    split falls back to the primitive's position in the sorted order) and a long diagonal strip of slivers (boxes that overlap
+    everything along the diagonal). The structure must stay within the traversal stack (StackOverflows 0, depth reported), agree
+    with the device's brute-force loop on every bounce ray, and the image must be the oracle's brute-force image bit for bit."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 64, 48
+    rng = np.random.default_rng(99)
+    # (a) 3000 triangles around one centroid: random orientations and sizes, each vertex triple sums to the same point
+    n_a = 3000
+    c = np.array([0.0, 0.2, 2.0])
+    a = rng.standard_normal((n_a, 3)); b = rng.standard_normal((n_a, 3))
+    r = (0.05 + 0.6 * rng.random((n_a, 1)))
+    v0 = c + r * a; v1 = c + r * b; v2 = c - r * (a + b)                    # v0 + v1 + v2 = 3 c
+    pos_a = np.stack([v0, v1, v2], 1).reshape(-1, 3)
+    idx_a = np.arange(3 * n_a)
+    # (b) a diagonal strip of 1500 sliver quads from (-2,-1,0.5) to (2,1.5,4.5), 1 mm wide
+    n_b = 1500
+    t = np.linspace(0.0, 1.0, n_b + 1)[:, None]
+    p = np.array([-2.0, -1.0, 0.5]) + t * np.array([4.0, 2.5, 4.0])
+    off = np.array([0.001, -0.001, 0.0])
+    pos_b = np.concatenate([p, p + off], 0)
+    i0 = np.arange(n_b)
+    idx_b = np.stack([i0, i0 + 1, i0 + n_b + 1, i0 + 1, i0 + n_b + 2, i0 + n_b + 1], -1).reshape(-1)
+    mat_a = S.material((0.7, 0.5, 0.3), metallic=0.0, roughness=0.6)
+    mat_b = S.material((0.9, 0.9, 0.9), metallic=1.0, roughness=0.2)
+    meshes = [S.Mesh(S.make_vertices(pos_a), S.make_indices(idx_a), False, mat_a),
+              S.Mesh(S.make_vertices(pos_b), S.make_indices(idx_b), False, mat_b)]
+    cam = S.make_camera((0, 0.2, -1.0), hfov_deg=80.0, aspect=W / H)
+    scene = S.Scene([S.MeshNode(meshes)], [S.RenderObject(0, S.trs()), S.RenderObject(0, S.trs((0.4, -0.3, 1.0), 40.0, (0.5, 0.5, 0.5)))],
+                    cam, S.make_scene_data((0.6, 0.7, 0.9, 1.0)), name="pathological").finalize()
+    gs = S.graphics_settings(W, H, spp=2, bounces=4, frame_index=5)
+
+    out, cnt = gpu_render(ptamd, gpu, scene, gs, W, H)
+    ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)      # brute force: no BVH of its own to trust
+    assert cnt.StackOverflows == 0
+    assert cnt.PrimaryRays + cnt.SecondaryRays == ref_rays and cnt.SecondaryRays > W * H // 4
+    assert_gbuffer_identical(out, ref_gb)
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+
+    # the same frame with the device validator: both traversals per bounce ray, disagreements counted
+    gpu.set_sharding(0, 1, 16)
+    g = ptamd.Scene(gpu, scene)
+    r = ptamd.Renderer(gpu, g, W, H)
+    st = gpu.accel_stats()
+    assert 0 < st.MaxBottomLevelDepth <= 28                                 # 6000 triangles: a balanced wide tree is 4-5 deep; the stack allows 2 * (tlas + blas) + 4 <= 64
+    gpu.set_debug_flags(2); gpu.reset_counters()
+    r.render(gs); gpu.sync()
+    c2 = gpu.counters()
+    gpu.set_debug_flags(0)
+    g.close()
+    assert c2.BvhMismatches == 0 and c2.StackOverflows == 0
+
+
 def test_traversal_schedules_agree(gpu, ptamd, pkg):
     """The three schedules of the bounce-ray traversal (flat instance scan with wave-compacted work items, phase-aligned TLAS
     walk, interleaved TLAS/BLAS) share tri_test / is_better, and a round is either one fused launch (k_round) or the
