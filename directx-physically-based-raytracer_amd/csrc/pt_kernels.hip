@@ -354,7 +354,7 @@ constexpr uint32_t kCountStride = 3u * kSubQueues;      // per round: entries tr
 PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(alive);
+    const unsigned long long m = wave_ballot(alive);
     const uint32_t prefix = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) lds[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -375,7 +375,7 @@ PT_DEV void block_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counter
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    const unsigned long long ma = wave_ballot(a), mb = wave_ballot(b);
     if (lane == 0) { lds[wave] = (uint32_t)__popcll(ma); lds[4 + wave] = (uint32_t)__popcll(mb); }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     uint32_t prof[13] = { 0 };
 #endif
     while (true) {
-        const unsigned long long busy = __ballot(qi != ~0u);
+        const unsigned long long busy = wave_ballot(qi != ~0u);
 #ifdef PT_STREAM_PROF
         prof[12]++;
 #endif
@@ -902,14 +902,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             const bool wantNode = live && G.y > 0x00FFFFFFu;
             const bool leaf = live && T.y != 0u;
             // which sections run this step: the one most lanes wait for, and any other with enough lanes of its own
-            const uint32_t nNode = (uint32_t)__popcll(__ballot(wantNode)), nTri = (uint32_t)__popcll(__ballot(leaf && !top)),
-                           nEnter = (uint32_t)__popcll(__ballot(leaf && top));
+            const uint32_t nNode = (uint32_t)__popcll(wave_ballot(wantNode)), nTri = (uint32_t)__popcll(wave_ballot(leaf && !top)),
+                           nEnter = (uint32_t)__popcll(wave_ballot(leaf && top));
             const uint32_t most = max(nNode, max(nTri, nEnter));
             const uint32_t lim = max(kStreamMinLanes, most >> kStreamShareShift);
             const bool doNode = nNode >= lim || nNode == most, doTri = nTri >= lim || nTri == most, doEnter = nEnter >= lim || nEnter == most;
 #ifdef PT_STREAM_PROF
             {
-                const uint32_t nLive = (uint32_t)__popcll(__ballot(live));
+                const uint32_t nLive = (uint32_t)__popcll(wave_ballot(live));
                 prof[0]++; prof[7] += nLive;
                 if (doNode && nNode) { prof[1]++; prof[2] += nNode; }
                 if (doTri && nTri) { prof[3]++; prof[4] += nTri; }
@@ -935,10 +935,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             }
             // ---- all loads of the step (a wave-cooperative gather through LDS -- neighbouring lanes fetching neighbouring 16-byte
             // units of one record -- was tried here and lost 30 %: the walk is bound by VALU issue, not by the vector cache)
-            f4v L0 = (f4v){ 0, 0, 0, 0 }, L1 = L0, L2 = L0, L3 = L0, L4 = L0, L5 = L0;
-            if (act == 1u || act == 2u || act == 4u) { L0 = blob.ld(addr); L1 = blob.ld(addr + 1); L2 = blob.ld(addr + 2); }
-            if (act == 1u || act == 4u) { L3 = blob.ld(addr + 3); L4 = blob.ld(addr + 4); }
-            if (act == 4u) L5 = blob.ld(addr + 5);
+            // (registers of lanes that do not load stay undefined and are not read: no zero fill; one address, immediate offsets)
+            f4v L0 = undefined_f4v(), L1 = undefined_f4v(), L2 = undefined_f4v(), L3 = undefined_f4v(), L4 = undefined_f4v(), L5 = undefined_f4v();
+            const f4v* rec = blob.p + addr;
+            if (act != 0u) { L0 = rec[0]; L1 = rec[1]; L2 = rec[2]; }
+            if (act == 1u || act == 4u) { L3 = rec[3]; L4 = rec[4]; }
+            if (act == 4u) L5 = rec[5];
             // ---- sections
             if (act == 1u) {
                 if (STATS) st.nodes++;

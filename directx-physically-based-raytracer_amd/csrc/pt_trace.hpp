@@ -25,6 +25,11 @@
 
 namespace pt {
 
+// The lanes of the wave for which the predicate holds. HIP's __ballot goes through an integer compare of a materialised 0/1
+// (v_cndmask + v_cmp per call); the builtin takes the condition mask as it is.
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+
 struct alignas(16) WideNode {
     float origin[3]; uint32_t expImask;
     uint32_t childBase, triBase, meta[2];
@@ -139,6 +144,14 @@ PT_DEV BoxRay box_ray(v3 o, v3 d)
 }
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+// Four registers with no defined content and no instruction spent on them: for values that only the lanes which load them go on
+// to read (a plain uninitialised variable is filled with zeros by the compiler where control flow merges).
+PT_DEV f4v undefined_f4v()
+{
+    float a, b, c, d;
+    asm volatile("" : "=v"(a)); asm volatile("" : "=v"(b)); asm volatile("" : "=v"(c)); asm volatile("" : "=v"(d));   // volatile: identical empty statements are not merged into one value (which would be copied around)
+    return (f4v){ a, b, c, d };
+}
 PT_DEV float ubyte_f(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xFFu); }          // v_cvt_f32_ubyte{0..3}
 
 // Slab test of a ray against the eight quantised child boxes of a node. Returns the paper's hit mask: bit 24 + (s ^ octinv)

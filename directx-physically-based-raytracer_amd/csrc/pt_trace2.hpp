@@ -191,10 +191,10 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
             }
         }
         // ---------------- phase B: the wave's candidates as compacted work items, batch by batch
-        for (uint32_t k = 0; __ballot(nCand > k) != 0ull; ) {                // k: levels (k-th candidate of every lane) done; uniform
+        for (uint32_t k = 0; wave_ballot(nCand > k) != 0ull; ) {                // k: levels (k-th candidate of every lane) done; uniform
             uint32_t total = 0, k2 = k;
             while (true) {
-                const unsigned long long bb = __ballot(nCand > k2);
+                const unsigned long long bb = wave_ballot(nCand > k2);
                 const uint32_t n = (uint32_t)__builtin_popcountll(bb);
                 if (n == 0u || total + n > kPhasedItems) break;
                 if (nCand > k2) items[total + (uint32_t)__builtin_popcountll(bb & ltMask)] = lane | (cand[k2 * 256] << 8);
@@ -209,14 +209,14 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
             __builtin_amdgcn_wave_barrier();
             uint32_t off = 0;
             for (uint32_t kk = k; kk < k2; kk++) {
-                const unsigned long long bb = __ballot(nCand > kk);
+                const unsigned long long bb = wave_ballot(nCand > kk);
                 if (nCand > kk) merge_item(h, tmin, results[off + (uint32_t)__builtin_popcountll(bb & ltMask)], cand[kk * 256]);
                 off += (uint32_t)__builtin_popcountll(bb);
             }
             __builtin_amdgcn_wave_barrier();
             k = k2;
         }
-        if (!__ballot(!tlasDone)) break;                                    // the wave leaves together: finished lanes keep serving items
+        if (!wave_ballot(!tlasDone)) break;                                    // the wave leaves together: finished lanes keep serving items
     }
     stats->overflow += stack.overflow;
     if (h.inst != ~0u && !(h.t < tmax)) h.inst = ~0u;
@@ -274,7 +274,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
     f4v* results = (f4v*)(ldsWave + 64u * 32u);                             // [item]: t u v slot
     uint32_t* items = (uint32_t*)(ldsWave + 64u * 32u + kFlatItems * 16u);  // [item]: lane | instance << 8
     const uint32_t nm = (uint32_t)__builtin_popcount(meshes), nq = (uint32_t)__builtin_popcount(quads);
-    if (!__ballot((nm | nq) != 0u)) return h;
+    if (!wave_ballot((nm | nq) != 0u)) return h;
     rays[2 * lane] = (f4v){ o.x, o.y, o.z, tmin };
     uint2 spill[kStackSize - kStackLdsFlat];
     GroupStack<kStackLdsFlat> stack; stack.init(ldsStack, spill);
@@ -287,7 +287,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
         {
             uint32_t mb = meshes, qb = quads;
             while (true) {
-                const unsigned long long bb = __ballot(nm > km2);
+                const unsigned long long bb = wave_ballot(nm > km2);
                 const uint32_t n = (uint32_t)__builtin_popcountll(bb);
                 if (n == 0u || total + n > kFlatItems) break;
                 if (nm > km2) {
@@ -296,9 +296,9 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
                 }
                 total += n; km2++;
             }
-            if (!__ballot(nm > km2)) {                                      // every mesh level is in: quads may follow
+            if (!wave_ballot(nm > km2)) {                                      // every mesh level is in: quads may follow
                 while (true) {
-                    const unsigned long long bb = __ballot(nq > kq2);
+                    const unsigned long long bb = wave_ballot(nq > kq2);
                     const uint32_t n = (uint32_t)__builtin_popcountll(bb);
                     if (n == 0u || total + n > kFlatItems) break;
                     if (nq > kq2) {
@@ -328,7 +328,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
             for (uint32_t pass = 0; pass < 2u; pass++) {
                 const uint32_t ka = pass == 0u ? km : kq, kb = pass == 0u ? km2 : kq2, mine = pass == 0u ? nm : nq;
                 for (uint32_t kk = ka; kk < kb; kk++) {
-                    const unsigned long long bb = __ballot(mine > kk);
+                    const unsigned long long bb = wave_ballot(mine > kk);
                     if (mine > kk) {
                         uint32_t x;
                         if (pass == 0u) { x = (uint32_t)__builtin_ctz(meshes); meshes &= meshes - 1u; }
