@@ -31,7 +31,7 @@ PT_DEV RayDesc generate_pinhole_ray(const PtCamera& cam, uint32_t px, uint32_t p
     v = ((float)py + 0.5f + cam.Jitter[1]) / (float)H;
     float nx = u * 2.0f + -1.0f, ny = v * -2.0f + 1.0f;
     v3 R = V3(cam.RightDirection), U = V3(cam.UpDirection), F = V3(cam.ForwardDirection);
-    v3 d = V3(nx * R.x + ny * U.x + F.x, nx * R.y + ny * U.y + F.y, nx * R.z + ny * U.z + F.z);
+    v3 d = V3(mad(ny, U.x, mad(nx, R.x, F.x)), mad(ny, U.y, mad(nx, R.y, F.y)), mad(ny, U.z, mad(nx, R.z, F.z)));
     RayDesc r;
     r.o = V3(cam.Position);
     r.d = normalize(d);
@@ -52,7 +52,7 @@ PT_DEV v3 environment_light_color(const SceneView& sv, const PtSceneData& sd, v3
 {
     if (sd.EnvironmentLightTextureDescriptor != ~0u) {
         const float* M = sd.EnvironmentLightTransform;
-        const v3 w = normalize(V3(M[0] * dir.x + M[1] * dir.y + M[2] * dir.z, M[4] * dir.x + M[5] * dir.y + M[6] * dir.z, M[8] * dir.x + M[9] * dir.y + M[10] * dir.z));
+        const v3 w = normalize(V3(sop3(M[0], dir.x, M[1], dir.y, M[2], dir.z), sop3(M[4], dir.x, M[5], dir.y, M[6], dir.z), sop3(M[8], dir.x, M[9], dir.y, M[10], dir.z)));
         const HeapEntry t = sv.heap[sd.EnvironmentLightTextureDescriptor];
         f4 c;
         if (sd.IsEnvironmentLightTextureCubeMap) c = cube_sample(t, sv.srgbLut, w);
@@ -67,7 +67,7 @@ PT_DEV v3 environment_light_color(const SceneView& sv, const PtSceneData& sd, v3
 // row-vector transform by an XMFLOAT4X4 (HLSL mul(M, float4(p,1)) on the column-major view of it)
 PT_DEV void xform4(const float* M, v3 p, float out[4])
 {
-    for (int j = 0; j < 4; j++) out[j] = p.x * M[j] + p.y * M[4 + j] + p.z * M[8 + j] + M[12 + j];
+    for (int j = 0; j < 4; j++) out[j] = sop3t(p.x, M[j], p.y, M[4 + j], p.z, M[8 + j], M[12 + j]);
 }
 
 struct SurfaceHit {               // the part of HitInfo (Shaders/HitInfo.hlsli:7-22) this path consumes
@@ -151,10 +151,8 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
             const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + nOff);
             nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
-        v3 n = (nrm[0] + (nrm[1] - nrm[0]) * bu) + (nrm[2] - nrm[0]) * bv;          // Vertex::Interpolate, Vertex.hlsli:63-72
-        v3 g = V3(W[0] * n.x + W[4] * n.y + W[8]  * n.z,
-                  W[1] * n.x + W[5] * n.y + W[9]  * n.z,
-                  W[2] * n.x + W[6] * n.y + W[10] * n.z);
+        v3 n = interp3(nrm[0], nrm[1], nrm[2], bu, bv);          // Vertex::Interpolate, Vertex.hlsli:63-72
+        v3 g = V3(sop3(W[0], n.x, W[4], n.y, W[8], n.z), sop3(W[1], n.x, W[5], n.y, W[9], n.z), sop3(W[2], n.x, W[6], n.y, W[10], n.z));
         h.GeometricNormal = normalize(g);
     } else {                                               // HitInfo.hlsli:37-50
         h.GeometricNormal = h.FlatNormal;
@@ -175,8 +173,8 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
             const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + tOff);
             tg[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
-        const v3 t = (tg[0] + (tg[1] - tg[0]) * bu) + (tg[2] - tg[0]) * bv;
-        h.Tangent = normalize(V3(M[0] * t.x + M[1] * t.y + M[2] * t.z, M[4] * t.x + M[5] * t.y + M[6] * t.z, M[8] * t.x + M[9] * t.y + M[10] * t.z));
+        const v3 t = interp3(tg[0], tg[1], tg[2], bu, bv);
+        h.Tangent = normalize(V3(sop3(M[0], t.x, M[1], t.y, M[2], t.z), sop3(M[4], t.x, M[5], t.y, M[6], t.z), sop3(M[8], t.x, M[9], t.y, M[10], t.z)));
     }
     get_texture_coordinates(od, sv.heap, prim, bu, bv, h.TextureCoordinates);      // :124-130
 }
@@ -280,9 +278,9 @@ __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtC
                             const uint32_t vi = load_index_dev(ib.ptr, ib.stride, 3 * h.PrimitiveIndex + kk);
                             m3[kk] = V3(f16_to_f32(mvb[4 * (size_t)vi]), f16_to_f32(mvb[4 * (size_t)vi + 1]), f16_to_f32(mvb[4 * (size_t)vi + 2]));
                         }
-                        q = q + ((m3[0] + (m3[1] - m3[0]) * hit.u) + (m3[2] - m3[0]) * hit.v);
+                        q = q + interp3(m3[0], m3[1], m3[2], hit.u, hit.v);
                     }
-                    prev = V3(P[0] * q.x + P[1] * q.y + P[2] * q.z + P[3], P[4] * q.x + P[5] * q.y + P[6] * q.z + P[7], P[8] * q.x + P[9] * q.y + P[10] * q.z + P[11]);
+                    prev = V3(sop3t(P[0], q.x, P[1], q.y, P[2], q.z, P[3]), sop3t(P[4], q.x, P[5], q.y, P[6], q.z, P[7]), sop3t(P[8], q.x, P[9], q.y, P[10], q.z, P[11]));
                 }
                 float clip[4], view[4];
                 xform4(cam.PreviousWorldToProjection, prev, clip);
@@ -957,8 +955,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
                 const uint32_t ntri = __float_as_uint(L5.y);
                 if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
-                    const v3 ro = V3(L0.x * wo.x + L0.y * wo.y + L0.z * wo.z + L0.w, L1.x * wo.x + L1.y * wo.y + L1.z * wo.z + L1.w, L2.x * wo.x + L2.y * wo.y + L2.z * wo.z + L2.w);
-                    const v3 rd = V3(L0.x * wd.x + L0.y * wd.y + L0.z * wd.z, L1.x * wd.x + L1.y * wd.y + L1.z * wd.z, L2.x * wd.x + L2.y * wd.y + L2.z * wd.z);
+                    const v3 ro = V3(sop3t(L0.x, wo.x, L0.y, wo.y, L0.z, wo.z, L0.w), sop3t(L1.x, wo.x, L1.y, wo.y, L1.z, wo.z, L1.w), sop3t(L2.x, wo.x, L2.y, wo.y, L2.z, wo.z, L2.w));
+                    const v3 rd = V3(sop3(L0.x, wd.x, L0.y, wd.y, L0.z, wd.z), sop3(L1.x, wd.x, L1.y, wd.y, L1.z, wd.z), sop3(L2.x, wd.x, L2.y, wd.y, L2.z, wd.z));
                     rs = ray_setup(rd);
                     br = box_ray(ro, rd);
                     nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;

@@ -6,8 +6,9 @@
 //     submodule that is absent from the reference tree. They are implemented here
 //     from the published algorithms MathLib cites; DESIGN.md "Arithmetic spec" lists each one.
 //
-// Arithmetic rules: compiled with -ffp-contract=off, so a*b+c is two roundings; the
-// only fused operations are the explicit __builtin_fmaf calls. dot() sums left to right.
+// Arithmetic rules: compiled with -ffp-contract=off, so the compiler fuses nothing; the
+// only fused operations are the explicit mad() / __builtin_fmaf calls: sums of products (dot, matrix rows,
+// cross, interpolation, polynomials) and the reference's `precise` mad code.
 // Division and sqrt are IEEE correctly rounded (hipcc default). No libm transcendental is used on
 // the Cornell-box path: sin/cos(2*pi*u) come from sincos_2pi() below.
 #pragma once
@@ -28,8 +29,17 @@ PT_DEV v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
 PT_DEV v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
 PT_DEV v3 vabs(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
-PT_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-PT_DEV v3 cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// Sums of products (arithmetic spec): the first product is rounded, every further term is one fused multiply-add,
+// terms taken left to right. mad(a, b, c) = a * b + c with one rounding.
+PT_DEV float mad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV float sop3(float a0, float b0, float a1, float b1, float a2, float b2) { return mad(a2, b2, mad(a1, b1, a0 * b0)); }                     // a0 b0 + a1 b1 + a2 b2
+PT_DEV float sop3t(float a0, float b0, float a1, float b1, float a2, float b2, float t) { return mad(a2, b2, mad(a1, b1, mad(a0, b0, t))); }   // ... + t (affine row)
+PT_DEV float dot(v3 a, v3 b) { return sop3(a.x, b.x, a.y, b.y, a.z, b.z); }
+PT_DEV v3 cross(v3 a, v3 b) { return V3(mad(a.y, b.z, -(a.z * b.y)), mad(a.z, b.x, -(a.x * b.z)), mad(a.x, b.y, -(a.y * b.x))); }
+PT_DEV v3 madd(v3 a, float s, v3 b) { return V3(mad(a.x, s, b.x), mad(a.y, s, b.y), mad(a.z, s, b.z)); }                                         // a * s + b
+// Vertex::Interpolate (Vertex.hlsli:63-72): a0 + (a1 - a0) * u + (a2 - a0) * v
+PT_DEV float interp1(float a0, float a1, float a2, float u, float v) { return mad(a2 - a0, v, mad(a1 - a0, u, a0)); }
+PT_DEV v3 interp3(v3 a0, v3 a1, v3 a2, float u, float v) { return V3(interp1(a0.x, a1.x, a2.x, u, v), interp1(a0.y, a1.y, a2.y, u, v), interp1(a0.z, a1.z, a2.z, u, v)); }
 PT_DEV v3 normalize(v3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
 PT_DEV float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 PT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -55,17 +65,17 @@ PT_DEV void sincos_2pi(float u, float& s, float& c)
     float x = r * 1.57079632679489662f;
     float x2 = x * x;
     float sp = 2.75573192e-6f;
-    sp = sp * x2 + -1.98412698e-4f;
-    sp = sp * x2 + 8.33333333e-3f;
-    sp = sp * x2 + -1.66666667e-1f;
-    sp = sp * x2 + 1.0f;
+    sp = mad(sp, x2, -1.98412698e-4f);
+    sp = mad(sp, x2, 8.33333333e-3f);
+    sp = mad(sp, x2, -1.66666667e-1f);
+    sp = mad(sp, x2, 1.0f);
     sp = sp * x;
     float cp = -2.75573192e-7f;
-    cp = cp * x2 + 2.48015873e-5f;
-    cp = cp * x2 + -1.38888889e-3f;
-    cp = cp * x2 + 4.16666667e-2f;
-    cp = cp * x2 + -0.5f;
-    cp = cp * x2 + 1.0f;
+    cp = mad(cp, x2, 2.48015873e-5f);
+    cp = mad(cp, x2, -1.38888889e-3f);
+    cp = mad(cp, x2, 4.16666667e-2f);
+    cp = mad(cp, x2, -0.5f);
+    cp = mad(cp, x2, 1.0f);
     int q = ((int)k) & 3;
     s = q == 0 ? sp : (q == 1 ? cp : (q == 2 ? -sp : -cp));
     c = q == 0 ? cp : (q == 1 ? -sp : (q == 2 ? -cp : sp));
@@ -158,9 +168,9 @@ PT_DEV basis3 ml_get_basis(v3 N)              // branchless ONB (Duff et al., JC
 PT_DEV v3 rotate_vector(const basis3& m, v3 v) { return V3(dot(m.T, v), dot(m.B, v), dot(m.N, v)); }
 PT_DEV v3 rotate_vector_inv(const basis3& m, v3 v)
 {
-    return V3(m.T.x * v.x + m.B.x * v.y + m.N.x * v.z,
-              m.T.y * v.x + m.B.y * v.y + m.N.y * v.z,
-              m.T.z * v.x + m.B.z * v.y + m.N.z * v.z);
+    return V3(sop3(m.T.x, v.x, m.B.x, v.y, m.N.x, v.z),
+              sop3(m.T.y, v.x, m.B.y, v.y, m.N.y, v.z),
+              sop3(m.T.z, v.x, m.B.z, v.y, m.N.z, v.z));
 }
 
 // ---- [MathLib] ImportanceSampling / BRDF ---------------------------------------------------
@@ -214,23 +224,23 @@ PT_DEV v3 ml_env_term_rtg(v3 F0, float NoV, float roughness)     // RTG ch.32 ra
     float m = roughness * roughness;
     float X1 = NoV, X2 = NoV * NoV, X3 = NoV * X2;
     float Y1 = m, Y3 = m * (m * m);
-    float b0 = 0.99044f + -1.28514f * X1;
-    float b1 = 1.29678f + -0.755907f * X1;
-    float bn = b0 + b1 * Y1;
-    float c0 = 1.0f + 2.92338f * X1 + 59.4188f * X3;
-    float c1 = 20.3225f + -27.0302f * X1 + 222.592f * X3;
-    float c2 = 121.563f + 626.13f * X1 + 316.627f * X3;
-    float bd = c0 + c1 * Y1 + c2 * Y3;
+    float b0 = mad(-1.28514f, X1, 0.99044f);
+    float b1 = mad(-0.755907f, X1, 1.29678f);
+    float bn = mad(b1, Y1, b0);
+    float c0 = mad(59.4188f, X3, mad(2.92338f, X1, 1.0f));
+    float c1 = mad(222.592f, X3, mad(-27.0302f, X1, 20.3225f));
+    float c2 = mad(316.627f, X3, mad(626.13f, X1, 121.563f));
+    float bd = mad(c2, Y3, mad(c1, Y1, c0));
     float bias = bn * ml_positive_rcp(bd);
-    float s0 = 0.0365463f + 3.32707f * X1;
-    float s1 = 9.0632f + -9.04756f * X1;
-    float sn = s0 + s1 * Y1;
-    float d0 = 1.0f + 3.59685f * X2 + -1.36772f * X3;
-    float d1 = 9.04401f + -16.3174f * X2 + 9.22949f * X3;
-    float d2 = 5.56589f + 19.7886f * X2 + -20.2123f * X3;
-    float sd = d0 + d1 * Y1 + d2 * Y3;
+    float s0 = mad(3.32707f, X1, 0.0365463f);
+    float s1 = mad(-9.04756f, X1, 9.0632f);
+    float sn = mad(s1, Y1, s0);
+    float d0 = mad(-1.36772f, X3, mad(3.59685f, X2, 1.0f));
+    float d1 = mad(9.22949f, X3, mad(-16.3174f, X2, 9.04401f));
+    float d2 = mad(-20.2123f, X3, mad(19.7886f, X2, 5.56589f));
+    float sd = mad(d2, Y3, mad(d1, Y1, d0));
     float scale = sn * ml_positive_rcp(sd);
-    return V3(saturate(F0.x * scale + bias), saturate(F0.y * scale + bias), saturate(F0.z * scale + bias));
+    return V3(saturate(mad(F0.x, scale, bias)), saturate(mad(F0.y, scale, bias)), saturate(mad(F0.z, scale, bias)));
 }
 PT_DEV v3 ml_vndf_get_ray(float u0, float u1, float roughness, v3 Vl)     // Dupuy & Benyoub 2023
 {

@@ -31,12 +31,10 @@ __global__ __launch_bounds__(256) void k_skin(const SkeletalVertex* __restrict__
     for (int j = 0; j < 4; j++) {
         const float* T = transforms + 12 * (size_t)sv.Joints[j];
         #pragma unroll
-        for (int k = 0; k < 12; k++) M[k] = M[k] + w[j] * T[k];
+        for (int k = 0; k < 12; k++) M[k] = mad(w[j], T[k], M[k]);
     }
     const float* pos = sv.Position;
-    const v3 p = V3(M[0] * pos[0] + M[1] * pos[1] + M[2] * pos[2] + M[3],
-                    M[4] * pos[0] + M[5] * pos[1] + M[6] * pos[2] + M[7],
-                    M[8] * pos[0] + M[9] * pos[1] + M[10] * pos[2] + M[11]);
+    const v3 p = V3(sop3t(M[0], pos[0], M[1], pos[1], M[2], pos[2], M[3]), sop3t(M[4], pos[0], M[5], pos[1], M[6], pos[2], M[7]), sop3t(M[8], pos[0], M[9], pos[1], M[10], pos[2], M[11]));
     float* dv = (float*)(vertices + 32 * (size_t)i);
     const v3 mv = V3(dv[0] - p.x, dv[1] - p.y, dv[2] - p.z);
     const v3 n = V3(unpack_r16_snorm(sv.Normal[0]), unpack_r16_snorm(sv.Normal[1]), unpack_r16_snorm(sv.Normal[2]));

@@ -57,10 +57,10 @@ PT_DEV f4 bilinear(const HeapEntry& t, const float* srgbLut, uint32_t face, floa
     const f4 c00 = texel_fetch(t, srgbLut, face, (uint32_t)x0, (uint32_t)y0), c10 = texel_fetch(t, srgbLut, face, (uint32_t)x1, (uint32_t)y0);
     const f4 c01 = texel_fetch(t, srgbLut, face, (uint32_t)x0, (uint32_t)y1), c11 = texel_fetch(t, srgbLut, face, (uint32_t)x1, (uint32_t)y1);
     f4 o;
-    { float top = c00.x * (1.0f - wx) + c10.x * wx, bot = c01.x * (1.0f - wx) + c11.x * wx; o.x = top * (1.0f - wy) + bot * wy; }
-    { float top = c00.y * (1.0f - wx) + c10.y * wx, bot = c01.y * (1.0f - wx) + c11.y * wx; o.y = top * (1.0f - wy) + bot * wy; }
-    { float top = c00.z * (1.0f - wx) + c10.z * wx, bot = c01.z * (1.0f - wx) + c11.z * wx; o.z = top * (1.0f - wy) + bot * wy; }
-    { float top = c00.w * (1.0f - wx) + c10.w * wx, bot = c01.w * (1.0f - wx) + c11.w * wx; o.w = top * (1.0f - wy) + bot * wy; }
+    { float top = mad(c10.x, wx, c00.x * (1.0f - wx)), bot = mad(c11.x, wx, c01.x * (1.0f - wx)); o.x = mad(bot, wy, top * (1.0f - wy)); }
+    { float top = mad(c10.y, wx, c00.y * (1.0f - wx)), bot = mad(c11.y, wx, c01.y * (1.0f - wx)); o.y = mad(bot, wy, top * (1.0f - wy)); }
+    { float top = mad(c10.z, wx, c00.z * (1.0f - wx)), bot = mad(c11.z, wx, c01.z * (1.0f - wx)); o.z = mad(bot, wy, top * (1.0f - wy)); }
+    { float top = mad(c10.w, wx, c00.w * (1.0f - wx)), bot = mad(c11.w, wx, c01.w * (1.0f - wx)); o.w = mad(bot, wy, top * (1.0f - wy)); }
     return o;
 }
 
@@ -115,7 +115,7 @@ PT_DEV void get_texture_coordinates(const PtObjectData* od, const HeapEntry* hea
             const PT_GLOBAL_AS uint16_t* h = gptr<uint16_t>((const uint8_t*)vb.ptr + (size_t)od->VertexDesc.Stride * idx + off);
             a[k][0] = f16_to_f32(h[0]); a[k][1] = f16_to_f32(h[1]);
         }
-        for (int c = 0; c < 2; c++) tc.uv[i][c] = a[0][c] + bu * (a[1][c] - a[0][c]) + bv * (a[2][c] - a[0][c]);
+        for (int c = 0; c < 2; c++) tc.uv[i][c] = interp1(a[0][c], a[1][c], a[2][c], bu, bv);
     }
 }
 
@@ -186,7 +186,7 @@ PT_DEV PtMaterial evaluate_material(v3& N, v3 T, const PtObjectData* od, const H
         const float nz = ml_sqrt01(1.0f - (nx * nx + ny * ny));
         const v3 Tn = normalize(T - N * dot(N, T));                                                 // Math::CalculateTBN, Math.hlsli:17-21
         const v3 B = cross(N, Tn);
-        N = normalize(V3(Tn.x * nx + B.x * ny + N.x * nz, Tn.y * nx + B.y * ny + N.y * nz, Tn.z * nx + B.z * ny + N.z * nz));
+        N = normalize(V3(sop3(Tn.x, nx, B.x, ny, N.x, nz), sop3(Tn.y, nx, B.y, ny, N.y, nz), sop3(Tn.z, nx, B.z, ny, N.z, nz)));
     }
     return m;
 }

@@ -302,12 +302,8 @@ PT_DEV void commit_candidate(const AlphaContext& ac, uint32_t flags, Hit& h, flo
 
 PT_DEV void transform_ray(const float* W, v3 o, v3 d, v3& ro, v3& rd)
 {
-    ro = V3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3],
-            W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7],
-            W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
-    rd = V3(W[0] * d.x + W[1] * d.y + W[2]  * d.z,
-            W[4] * d.x + W[5] * d.y + W[6]  * d.z,
-            W[8] * d.x + W[9] * d.y + W[10] * d.z);
+    ro = V3(sop3t(W[0], o.x, W[1], o.y, W[2], o.z, W[3]), sop3t(W[4], o.x, W[5], o.y, W[6], o.z, W[7]), sop3t(W[8], o.x, W[9], o.y, W[10], o.z, W[11]));
+    rd = V3(sop3(W[0], d.x, W[1], d.y, W[2], d.z), sop3(W[4], d.x, W[5], d.y, W[6], d.z), sop3(W[8], d.x, W[9], d.y, W[10], d.z));
 }
 
 // Debug / validation traversal (PT_DEBUG_BRUTE_FORCE): every triangle of every instance, no BVH.

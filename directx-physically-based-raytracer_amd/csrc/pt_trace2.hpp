@@ -101,12 +101,8 @@ PT_DEV f4v trace_item(const BlobReader<LDS>& blob, const BlobView& bv, const Alp
     }
     if (enter) {
         const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
-        const v3 ro = V3(w0.x * io.x + w0.y * io.y + w0.z * io.z + w0.w,
-                         w1.x * io.x + w1.y * io.y + w1.z * io.z + w1.w,
-                         w2.x * io.x + w2.y * io.y + w2.z * io.z + w2.w);
-        const v3 rd = V3(w0.x * id.x + w0.y * id.y + w0.z * id.z,
-                         w1.x * id.x + w1.y * id.y + w1.z * id.z,
-                         w2.x * id.x + w2.y * id.y + w2.z * id.z);
+        const v3 ro = V3(sop3t(w0.x, io.x, w0.y, io.y, w0.z, io.z, w0.w), sop3t(w1.x, io.x, w1.y, io.y, w1.z, io.z, w1.w), sop3t(w2.x, io.x, w2.y, io.y, w2.z, io.z, w2.w));
+        const v3 rd = V3(sop3(w0.x, id.x, w0.y, id.y, w0.z, id.z), sop3(w1.x, id.x, w1.y, id.y, w1.z, id.z), sop3(w2.x, id.x, w2.y, id.y, w2.z, id.z));
         const RaySetup rs = ray_setup(rd);
         const BoxRay br = box_ray(ro, rd);
         const uint32_t triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
@@ -385,8 +381,8 @@ PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const A
                 const uint32_t ntri = __float_as_uint(mk.y), x = __float_as_uint(mk.w);
                 if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
                     const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
-                    ro = V3(w0.x * o.x + w0.y * o.y + w0.z * o.z + w0.w, w1.x * o.x + w1.y * o.y + w1.z * o.z + w1.w, w2.x * o.x + w2.y * o.y + w2.z * o.z + w2.w);
-                    const v3 rd = V3(w0.x * d.x + w0.y * d.y + w0.z * d.z, w1.x * d.x + w1.y * d.y + w1.z * d.z, w2.x * d.x + w2.y * d.y + w2.z * d.z);
+                    ro = V3(sop3t(w0.x, o.x, w0.y, o.y, w0.z, o.z, w0.w), sop3t(w1.x, o.x, w1.y, o.y, w1.z, o.z, w1.w), sop3t(w2.x, o.x, w2.y, o.y, w2.z, o.z, w2.w));
+                    const v3 rd = V3(sop3(w0.x, d.x, w0.y, d.y, w0.z, d.z), sop3(w1.x, d.x, w1.y, d.y, w1.z, d.z), sop3(w2.x, d.x, w2.y, d.y, w2.z, d.z));
                     rs = ray_setup(rd);
                     br = box_ray(ro, rd);
                     nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;

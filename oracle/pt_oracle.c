@@ -4,9 +4,11 @@
  * Scalar fp32 restatement of the reference path. Build: gcc -O2 -ffp-contract=off
  * (no implicit FMA; every fused multiply-add below is an explicit fmaf()).
  * Arithmetic conventions ("the spec", shared in WORDS with the HIP kernels, not in code):
- *   - dot(a,b) = a.x*b.x + a.y*b.y + a.z*b.z, left to right, unfused
+ *   - sums of products: first product rounded, every further term one fmaf, left to right:
+ *     dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)); matrix rows alike (affine rows: translation innermost);
+ *     cross, Vertex::Interpolate, bilinear filtering and polynomials as DESIGN.md section 1 lists them
  *   - normalize(v) = v * (1/sqrtf(dot(v,v))); rsqrt(x) = 1/sqrtf(x); all divisions IEEE
- *   - HLSL mad() inside `precise` code = fmaf(); everything else is mul then add
+ *   - HLSL mad() inside `precise` code = fmaf(); every other scalar expression is mul then add
  *   - sin/cos of 2*pi*u come from or_sincos_2pi() (explicit polynomial), never libm
  */
 #include "pt_oracle.h"
@@ -32,11 +34,20 @@ static inline f3 mul3(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); 
 static inline f3 scl3(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
 static inline f3 neg3(f3 a) { return F3(-a.x, -a.y, -a.z); }
 static inline f3 abs3(f3 a) { return F3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
-static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* Sums of products (arithmetic spec): the first product is rounded, every further term is one fused multiply-add (fmaf is exact
+ * in C), terms taken left to right. */
+static inline float mad(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float sop3(float a0, float b0, float a1, float b1, float a2, float b2) { return mad(a2, b2, mad(a1, b1, a0 * b0)); }
+static inline float sop3t(float a0, float b0, float a1, float b1, float a2, float b2, float t) { return mad(a2, b2, mad(a1, b1, mad(a0, b0, t))); }
+static inline float dot3(f3 a, f3 b) { return sop3(a.x, b.x, a.y, b.y, a.z, b.z); }
 static inline f3 cross3(f3 a, f3 b)
 {
-    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return F3(mad(a.y, b.z, -(a.z * b.y)), mad(a.z, b.x, -(a.x * b.z)), mad(a.x, b.y, -(a.y * b.x)));
 }
+static inline f3 madd3(f3 a, float s, f3 b) { return F3(mad(a.x, s, b.x), mad(a.y, s, b.y), mad(a.z, s, b.z)); }   /* a * s + b */
+/* Vertex::Interpolate (Vertex.hlsli:63-72): a0 + (a1 - a0) * u + (a2 - a0) * v */
+static inline float interp1(float a0, float a1, float a2, float u, float v) { return mad(a2 - a0, v, mad(a1 - a0, u, a0)); }
+static inline f3 interp3(f3 a0, f3 a1, f3 a2, float u, float v) { return F3(interp1(a0.x, a1.x, a2.x, u, v), interp1(a0.y, a1.y, a2.y, u, v), interp1(a0.z, a1.z, a2.z, u, v)); }
 static inline f3 normalize3(f3 v) { float inv = 1.0f / sqrtf(dot3(v, v)); return scl3(v, inv); }
 static inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -64,17 +75,17 @@ void or_sincos_2pi(float u, float* s, float* c)
     float x = r * 1.57079632679489662f;      /* * pi/2 */
     float x2 = x * x;
     float sp = 2.75573192e-6f;               /* 1/9! */
-    sp = sp * x2 + -1.98412698e-4f;          /* -1/7! */
-    sp = sp * x2 + 8.33333333e-3f;           /* 1/5! */
-    sp = sp * x2 + -1.66666667e-1f;          /* -1/3! */
-    sp = sp * x2 + 1.0f;
+    sp = mad(sp, x2, -1.98412698e-4f);          /* -1/7! */
+    sp = mad(sp, x2, 8.33333333e-3f);           /* 1/5! */
+    sp = mad(sp, x2, -1.66666667e-1f);          /* -1/3! */
+    sp = mad(sp, x2, 1.0f);
     sp = sp * x;
     float cp = -2.75573192e-7f;              /* -1/10! */
-    cp = cp * x2 + 2.48015873e-5f;           /* 1/8! */
-    cp = cp * x2 + -1.38888889e-3f;          /* -1/6! */
-    cp = cp * x2 + 4.16666667e-2f;           /* 1/4! */
-    cp = cp * x2 + -0.5f;
-    cp = cp * x2 + 1.0f;
+    cp = mad(cp, x2, 2.48015873e-5f);           /* 1/8! */
+    cp = mad(cp, x2, -1.38888889e-3f);          /* -1/6! */
+    cp = mad(cp, x2, 4.16666667e-2f);           /* 1/4! */
+    cp = mad(cp, x2, -0.5f);
+    cp = mad(cp, x2, 1.0f);
     int q = ((int)k) & 3;
     if (q == 0) { *s = sp; *c = cp; }
     else if (q == 1) { *s = cp; *c = -sp; }
@@ -207,9 +218,9 @@ static basis3 ml_get_basis(f3 N)
 static inline f3 rotate_vector(basis3 m, f3 v) { return F3(dot3(m.T, v), dot3(m.B, v), dot3(m.N, v)); }
 static inline f3 rotate_vector_inv(basis3 m, f3 v)
 {
-    return F3(m.T.x * v.x + m.B.x * v.y + m.N.x * v.z,
-              m.T.y * v.x + m.B.y * v.y + m.N.y * v.z,
-              m.T.z * v.x + m.B.z * v.y + m.N.z * v.z);
+    return F3(sop3(m.T.x, v.x, m.B.x, v.y, m.N.x, v.z),
+              sop3(m.T.y, v.x, m.B.y, v.y, m.N.y, v.z),
+              sop3(m.T.z, v.x, m.B.z, v.y, m.N.z, v.z));
 }
 
 /* ImportanceSampling::Cosine::GetRay / GetPDF */
@@ -270,25 +281,25 @@ void or_env_term_rtg(const float f0[3], float NoV, float roughness, float out[3]
     float X1 = NoV, X2 = NoV * NoV, X3 = NoV * X2;
     float Y1 = m, Y2 = m * m, Y3 = m * Y2;
     /* bias = dot(M1*X.xy, Y.xy) / dot(M2*X.xyw, Y.xyw) */
-    float b0 = 0.99044f + -1.28514f * X1;
-    float b1 = 1.29678f + -0.755907f * X1;
-    float bn = b0 + b1 * Y1;
-    float c0 = 1.0f + 2.92338f * X1 + 59.4188f * X3;
-    float c1 = 20.3225f + -27.0302f * X1 + 222.592f * X3;
-    float c2 = 121.563f + 626.13f * X1 + 316.627f * X3;
-    float bd = c0 + c1 * Y1 + c2 * Y3;
+    float b0 = mad(-1.28514f, X1, 0.99044f);
+    float b1 = mad(-0.755907f, X1, 1.29678f);
+    float bn = mad(b1, Y1, b0);
+    float c0 = mad(59.4188f, X3, mad(2.92338f, X1, 1.0f));
+    float c1 = mad(222.592f, X3, mad(-27.0302f, X1, 20.3225f));
+    float c2 = mad(316.627f, X3, mad(626.13f, X1, 121.563f));
+    float bd = mad(c2, Y3, mad(c1, Y1, c0));
     float bias = bn * ml_positive_rcp(bd);
     /* scale = dot(M3*X.xy, Y.xy) / dot(M4*X.xzw, Y.xyw) */
-    float s0 = 0.0365463f + 3.32707f * X1;
-    float s1 = 9.0632f + -9.04756f * X1;
-    float sn = s0 + s1 * Y1;
-    float d0 = 1.0f + 3.59685f * X2 + -1.36772f * X3;
-    float d1 = 9.04401f + -16.3174f * X2 + 9.22949f * X3;
-    float d2 = 5.56589f + 19.7886f * X2 + -20.2123f * X3;
-    float sd = d0 + d1 * Y1 + d2 * Y3;
+    float s0 = mad(3.32707f, X1, 0.0365463f);
+    float s1 = mad(-9.04756f, X1, 9.0632f);
+    float sn = mad(s1, Y1, s0);
+    float d0 = mad(-1.36772f, X3, mad(3.59685f, X2, 1.0f));
+    float d1 = mad(9.22949f, X3, mad(-16.3174f, X2, 9.04401f));
+    float d2 = mad(-20.2123f, X3, mad(19.7886f, X2, 5.56589f));
+    float sd = mad(d2, Y3, mad(d1, Y1, d0));
     float scale = sn * ml_positive_rcp(sd);
     (void)Y2;
-    for (int i = 0; i < 3; i++) out[i] = saturatef(f0[i] * scale + bias);
+    for (int i = 0; i < 3; i++) out[i] = saturatef(mad(f0[i], scale, bias));
 }
 
 /* ImportanceSampling::VNDF::GetRay: spherical-cap VNDF sampling (Dupuy & Benyoub 2023), returns local H */
@@ -668,9 +679,9 @@ static void bilinear(const OrHeapEntry* t, uint32_t face, float fx, float fy, in
     texel_fetch(t, face, (uint32_t)x0, (uint32_t)y0, c00); texel_fetch(t, face, (uint32_t)x1, (uint32_t)y0, c10);
     texel_fetch(t, face, (uint32_t)x0, (uint32_t)y1, c01); texel_fetch(t, face, (uint32_t)x1, (uint32_t)y1, c11);
     for (int c = 0; c < 4; c++) {
-        float top = c00[c] * (1.0f - wx) + c10[c] * wx;
-        float bot = c01[c] * (1.0f - wx) + c11[c] * wx;
-        out[c] = top * (1.0f - wy) + bot * wy;
+        float top = mad(c10[c], wx, c00[c] * (1.0f - wx));
+        float bot = mad(c11[c], wx, c01[c] * (1.0f - wx));
+        out[c] = mad(bot, wy, top * (1.0f - wy));
     }
 }
 
@@ -753,7 +764,7 @@ static OrMaterial evaluate_material(f3* N, f3 T, const OrObjectData* od, const O
         /* Math::CalculateTBN Math.hlsli:17-21 */
         f3 Tn = normalize3(sub3(T, scl3(*N, dot3(*N, T))));
         f3 B = cross3(*N, Tn);
-        f3 r = F3(Tn.x * nx + B.x * ny + N->x * nz, Tn.y * nx + B.y * ny + N->y * nz, Tn.z * nx + B.z * ny + N->z * nz);
+        f3 r = F3(sop3(Tn.x, nx, B.x, ny, N->x, nz), sop3(Tn.y, nx, B.y, ny, N->y, nz), sop3(Tn.z, nx, B.z, ny, N->z, nz));
         *N = normalize3(r);
     }
     return m;
@@ -774,7 +785,7 @@ static void get_texture_coordinates(const OrObjectData* od, const OrHeapEntry* h
             uint16_t h[2]; memcpy(h, (const uint8_t*)vb->Ptr + (size_t)od->VertexDesc.Stride * idx + off, 4);
             a[k][0] = or_f16_to_f32(h[0]); a[k][1] = or_f16_to_f32(h[1]);
         }
-        for (int c = 0; c < 2; c++) uv[i][c] = a[0][c] + bu * (a[1][c] - a[0][c]) + bv * (a[2][c] - a[0][c]);
+        for (int c = 0; c < 2; c++) uv[i][c] = interp1(a[0][c], a[1][c], a[2][c], bu, bv);
     }
 }
 
@@ -946,12 +957,8 @@ static inline void instance_intersect(const OrScene* s, uint32_t ii, f3 o, f3 d,
     const OrInstanceDesc* in = &s->inst[ii];
     if (!(in->InstanceMask & 0xFFu)) return;
     const float* W = &s->w2o[12 * ii];
-    f3 oo = F3(W[0] * o.x + W[1] * o.y + W[2]  * o.z + W[3],
-               W[4] * o.x + W[5] * o.y + W[6]  * o.z + W[7],
-               W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
-    f3 od = F3(W[0] * d.x + W[1] * d.y + W[2]  * d.z,
-               W[4] * d.x + W[5] * d.y + W[6]  * d.z,
-               W[8] * d.x + W[9] * d.y + W[10] * d.z);
+    f3 oo = F3(sop3t(W[0], o.x, W[1], o.y, W[2], o.z, W[3]), sop3t(W[4], o.x, W[5], o.y, W[6], o.z, W[7]), sop3t(W[8], o.x, W[9], o.y, W[10], o.z, W[11]));
+    f3 od = F3(sop3(W[0], d.x, W[1], d.y, W[2], d.z), sop3(W[4], d.x, W[5], d.y, W[6], d.z), sop3(W[8], d.x, W[9], d.y, W[10], d.z));
     blas_intersect(s, &s->blas[in->Blas], s->accel_mode, oo, od, tmin, ii, c);
 }
 
@@ -1168,8 +1175,8 @@ void or_trace_visibility(const OrScene* s, const float* rays, uint32_t count, fl
             const OrInstanceDesc* I = &s->inst[in];
             if (!(I->InstanceMask & 0xFFu)) continue;
             const float* W = &s->w2o[12 * in];
-            f3 oo = F3(W[0] * o.x + W[1] * o.y + W[2] * o.z + W[3], W[4] * o.x + W[5] * o.y + W[6] * o.z + W[7], W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11]);
-            f3 od = F3(W[0] * d.x + W[1] * d.y + W[2] * d.z, W[4] * d.x + W[5] * d.y + W[6] * d.z, W[8] * d.x + W[9] * d.y + W[10] * d.z);
+            f3 oo = F3(sop3t(W[0], o.x, W[1], o.y, W[2], o.z, W[3]), sop3t(W[4], o.x, W[5], o.y, W[6], o.z, W[7]), sop3t(W[8], o.x, W[9], o.y, W[10], o.z, W[11]));
+            f3 od = F3(sop3(W[0], d.x, W[1], d.y, W[2], d.z), sop3(W[4], d.x, W[5], d.y, W[6], d.z), sop3(W[8], d.x, W[9], d.y, W[10], d.z));
             RayObj ro; ray_setup(&ro, oo, od);
             const Blas* B = &s->blas[I->Blas];
             for (uint32_t k = 0; k < B->n_tris && !committed; k++) {
@@ -1200,10 +1207,8 @@ void or_skin_mesh(const void* skeletal, const float* transforms, void* vertices,
         memcpy(pos, sv, 12); memcpy(nq, sv + 12, 6); memcpy(tq, sv + 18, 6); memcpy(joints, sv + 24, 8); memcpy(wt, sv + 32, 16);
         const float w[4] = { wt[0], wt[1], wt[2], 1.0f - wt[0] - wt[1] - wt[2] };
         float M[12] = { 0 };
-        for (int j = 0; j < 4; j++) for (int k = 0; k < 12; k++) M[k] = M[k] + w[j] * transforms[12 * (size_t)joints[j] + k];
-        f3 p = F3(M[0] * pos[0] + M[1] * pos[1] + M[2] * pos[2] + M[3],
-                  M[4] * pos[0] + M[5] * pos[1] + M[6] * pos[2] + M[7],
-                  M[8] * pos[0] + M[9] * pos[1] + M[10] * pos[2] + M[11]);
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 12; k++) M[k] = mad(w[j], transforms[12 * (size_t)joints[j] + k], M[k]);
+        f3 p = F3(sop3t(M[0], pos[0], M[1], pos[1], M[2], pos[2], M[3]), sop3t(M[4], pos[0], M[5], pos[1], M[6], pos[2], M[7]), sop3t(M[8], pos[0], M[9], pos[1], M[10], pos[2], M[11]));
         float old[3]; memcpy(old, dv, 12);
         f3 mv = F3(old[0] - p.x, old[1] - p.y, old[2] - p.z);
         f3 n = F3(unpack_r16_snorm(nq[0]), unpack_r16_snorm(nq[1]), unpack_r16_snorm(nq[2]));
@@ -1262,11 +1267,9 @@ static int cast_ray(const OrScene* s, const RayDesc* ray, HitInfo* h)
             nrm[k] = F3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
         /* Vertex::Interpolate: a0 + b.x*(a1-a0) + b.y*(a2-a0) */
-        f3 n = add3(add3(nrm[0], scl3(sub3(nrm[1], nrm[0]), c.u)), scl3(sub3(nrm[2], nrm[0]), c.v));
+        f3 n = interp3(nrm[0], nrm[1], nrm[2], c.u, c.v);
         const float* W = &s->w2o[12 * c.inst];
-        f3 g = F3(W[0] * n.x + W[4] * n.y + W[8]  * n.z,
-                  W[1] * n.x + W[5] * n.y + W[9]  * n.z,
-                  W[2] * n.x + W[6] * n.y + W[10] * n.z);   /* RotateVectorInverse((float3x3)worldToObject, n) */
+        f3 g = F3(sop3(W[0], n.x, W[4], n.y, W[8], n.z), sop3(W[1], n.x, W[5], n.y, W[9], n.z), sop3(W[2], n.x, W[6], n.y, W[10], n.z));   /* RotateVectorInverse((float3x3)worldToObject, n) */
         h->GeometricNormal = normalize3(g);
     } else {                                             /* HitInfo.hlsli:37-50 */
         h->GeometricNormal = h->FlatNormal;
@@ -1281,9 +1284,9 @@ static int cast_ray(const OrScene* s, const RayDesc* ray, HitInfo* h)
             int16_t q[3]; memcpy(q, vbase + (size_t)stride * idx[k] + od->VertexDesc.Tangent, 6);
             tg[k] = F3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
-        f3 t = add3(add3(tg[0], scl3(sub3(tg[1], tg[0]), c.u)), scl3(sub3(tg[2], tg[0]), c.v));
+        f3 t = interp3(tg[0], tg[1], tg[2], c.u, c.v);
         const float* M = in->Transform;
-        f3 w = F3(M[0] * t.x + M[1] * t.y + M[2] * t.z, M[4] * t.x + M[5] * t.y + M[6] * t.z, M[8] * t.x + M[9] * t.y + M[10] * t.z);
+        f3 w = F3(sop3(M[0], t.x, M[1], t.y, M[2], t.z), sop3(M[4], t.x, M[5], t.y, M[6], t.z), sop3(M[8], t.x, M[9], t.y, M[10], t.z));
         h->Tangent = normalize3(w);
     }
     get_texture_coordinates(od, s->heap, c.prim, c.u, c.v, h->TextureCoordinates);       /* :124-130 */
@@ -1295,7 +1298,7 @@ static f3 environment_light_color(const OrScene* s, const OrSceneData* sd, f3 di
 {
     if (sd->EnvironmentLightTextureDescriptor != ~0u) {
         const float* M = sd->EnvironmentLightTransform;
-        f3 w = normalize3(F3(M[0] * dir.x + M[1] * dir.y + M[2] * dir.z, M[4] * dir.x + M[5] * dir.y + M[6] * dir.z, M[8] * dir.x + M[9] * dir.y + M[10] * dir.z));
+        f3 w = normalize3(F3(sop3(M[0], dir.x, M[1], dir.y, M[2], dir.z), sop3(M[4], dir.x, M[5], dir.y, M[6], dir.z), sop3(M[8], dir.x, M[9], dir.y, M[10], dir.z)));
         const OrHeapEntry* t = &s->heap[sd->EnvironmentLightTextureDescriptor];
         float out[4];
         if (sd->IsEnvironmentLightTextureCubeMap) { float d[3] = { w.x, w.y, w.z }; or_cube_sample(t, d, out); }
@@ -1318,7 +1321,7 @@ static RayDesc generate_pinhole_ray(const OrCamera* cam, uint32_t px, uint32_t p
     uv[0] = u; uv[1] = v;
     float nx = u * 2.0f + -1.0f, ny = v * -2.0f + 1.0f;
     f3 R = ld3(cam->RightDirection), U = ld3(cam->UpDirection), F = ld3(cam->ForwardDirection);
-    f3 d = F3(nx * R.x + ny * U.x + F.x, nx * R.y + ny * U.y + F.y, nx * R.z + ny * U.z + F.z);
+    f3 d = F3(mad(ny, U.x, mad(nx, R.x, F.x)), mad(ny, U.y, mad(nx, R.y, F.y)), mad(ny, U.z, mad(nx, R.z, F.z)));
     RayDesc r;
     r.Origin = ld3(cam->Position);
     r.Direction = normalize3(d);
@@ -1331,7 +1334,7 @@ static RayDesc generate_pinhole_ray(const OrCamera* cam, uint32_t px, uint32_t p
 /* row-vector transform by an XMFLOAT4X4: out_j = p.x*M[0][j] + p.y*M[1][j] + p.z*M[2][j] + M[3][j] */
 static void xform4(const float M[16], f3 p, float out[4])
 {
-    for (int j = 0; j < 4; j++) out[j] = p.x * M[j] + p.y * M[4 + j] + p.z * M[8 + j] + M[12 + j];
+    for (int j = 0; j < 4; j++) out[j] = sop3t(p.x, M[j], p.y, M[4 + j], p.z, M[8 + j], M[12 + j]);
 }
 
 static inline f3 material_emission(const OrMaterial* m) { return scl3(ld3(m->EmissiveColor), m->EmissiveStrength); }
@@ -1388,10 +1391,10 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
                                     uint32_t vi = load_index(ib->Ptr, ib->Stride, 3 * h.PrimitiveIndex + kk);
                                     m3[kk] = F3(or_f16_to_f32(mvb[4 * vi]), or_f16_to_f32(mvb[4 * vi + 1]), or_f16_to_f32(mvb[4 * vi + 2]));
                                 }
-                                f3 mi = add3(add3(m3[0], scl3(sub3(m3[1], m3[0]), h.Bary[0])), scl3(sub3(m3[2], m3[0]), h.Bary[1]));
+                                f3 mi = interp3(m3[0], m3[1], m3[2], h.Bary[0], h.Bary[1]);
                                 q = add3(q, mi);
                             }
-                            prev = F3(P[0] * q.x + P[1] * q.y + P[2] * q.z + P[3], P[4] * q.x + P[5] * q.y + P[6] * q.z + P[7], P[8] * q.x + P[9] * q.y + P[10] * q.z + P[11]);
+                            prev = F3(sop3t(P[0], q.x, P[1], q.y, P[2], q.z, P[3]), sop3t(P[4], q.x, P[5], q.y, P[6], q.z, P[7]), sop3t(P[8], q.x, P[9], q.y, P[10], q.z, P[11]));
                         }
                         float clip[4], view[4];
                         xform4(cam->PreviousWorldToProjection, prev, clip);
