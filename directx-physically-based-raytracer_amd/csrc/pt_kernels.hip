@@ -457,7 +457,7 @@ PT_DEV void store_path(const PathQueue& q, uint32_t i, const PathRegs& p)
 // iteration (bounce == Bounces), which samples but never traces (:213).
 PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit& h, const BSDFSample& bs, v3 emission, v3 rayDir, v3& newO, v3& newD, int& lobe)
 {
-    p.srad = p.srad + p.thr * emission;                          // :320
+    p.srad = madd(p.thr, emission, p.srad);                       // :320
     const SurfaceVectors svec = surface_vectors(h.IsFrontFace, h.GeometricNormal, h.ShadingNormal);
     const v3 V = -rayDir;
     float w[3]; bs.ComputeLobeWeights(svec, V, gs.ExtFlags, w);
@@ -528,7 +528,7 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
     bool goes = false; int lobe = 0;
     if (aux && p.sample == 0 && p.bounce == 1) aux[p.pixel].x = hr.x == ~0u ? INFINITY : hitT;        // hitDistance, :235-239
     if (hr.x == ~0u) {                                       // :241-259
-        p.srad = p.srad + p.thr * environment_light_color(sv, sd, rayDir);
+        p.srad = madd(p.thr, environment_light_color(sv, sd, rayDir), p.srad);
     } else {                                                 // :293-304
         SurfaceHit h;
         reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);

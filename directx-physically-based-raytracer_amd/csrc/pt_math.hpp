@@ -37,6 +37,7 @@ PT_DEV float sop3t(float a0, float b0, float a1, float b1, float a2, float b2, f
 PT_DEV float dot(v3 a, v3 b) { return sop3(a.x, b.x, a.y, b.y, a.z, b.z); }
 PT_DEV v3 cross(v3 a, v3 b) { return V3(mad(a.y, b.z, -(a.z * b.y)), mad(a.z, b.x, -(a.x * b.z)), mad(a.x, b.y, -(a.y * b.x))); }
 PT_DEV v3 madd(v3 a, float s, v3 b) { return V3(mad(a.x, s, b.x), mad(a.y, s, b.y), mad(a.z, s, b.z)); }                                         // a * s + b
+PT_DEV v3 madd(v3 a, v3 s, v3 b) { return V3(mad(a.x, s.x, b.x), mad(a.y, s.y, b.y), mad(a.z, s.z, b.z)); }                                      // a * s + b, per component
 // Vertex::Interpolate (Vertex.hlsli:63-72): a0 + (a1 - a0) * u + (a2 - a0) * v
 PT_DEV float interp1(float a0, float a1, float a2, float u, float v) { return mad(a2 - a0, v, mad(a1 - a0, u, a0)); }
 PT_DEV v3 interp3(v3 a0, v3 a1, v3 a2, float u, float v) { return V3(interp1(a0.x, a1.x, a2.x, u, v), interp1(a0.y, a1.y, a2.y, u, v), interp1(a0.z, a1.z, a2.z, u, v)); }
@@ -178,7 +179,7 @@ PT_DEV v3 ml_cosine_get_ray(float u0, float u1)
 {
     float s, c; sincos_2pi(u0, s, c);
     float cosT = ml_sqrt01(u1);
-    float sinT = ml_sqrt01(1.0f - cosT * cosT);
+    float sinT = ml_sqrt01(mad(-cosT, cosT, 1.0f));
     return V3(sinT * c, sinT * s, cosT);
 }
 PT_DEV float ml_cosine_pdf(float NoL) { return PT_DIV_CONST(NoL, kPi); }
@@ -187,7 +188,7 @@ PT_DEV float ml_distribution_ggx(float roughness, float NoH)
 {
     float m = roughness * roughness;
     float m2 = m * m;
-    float t = (NoH * m2 - NoH) * NoH + 1.0f;
+    float t = mad(mad(NoH, m2, -NoH), NoH, 1.0f);
     float a = m / t;
     return PT_DIV_CONST(a * a, kPi);
 }
@@ -195,28 +196,28 @@ PT_DEV float ml_geometry_term_mod(float roughness, float NoL, float NoV)
 {
     float m = roughness * roughness;
     float m2 = m * m;
-    float a = NoL * ml_sqrt01((NoV - m2 * NoV) * NoV + m2);
-    float b = NoV * ml_sqrt01((NoL - m2 * NoL) * NoL + m2);
+    float a = NoL * ml_sqrt01(mad(mad(-m2, NoV, NoV), NoV, m2));
+    float b = NoV * ml_sqrt01(mad(mad(-m2, NoL, NoL), NoL, m2));
     return 0.5f * ml_positive_rcp(a + b);
 }
 PT_DEV v3 ml_fresnel_schlick(v3 F0, float VoH)
 {
     float f = ml_pow5_01(1.0f - VoH);
-    return V3(F0.x + (1.0f - F0.x) * f, F0.y + (1.0f - F0.y) * f, F0.z + (1.0f - F0.z) * f);
+    return V3(mad(1.0f - F0.x, f, F0.x), mad(1.0f - F0.y, f, F0.y), mad(1.0f - F0.z, f, F0.z));
 }
 PT_DEV float ml_fresnel_dielectric(float eta, float VoN)
 {
-    float saSq = eta * eta * (1.0f - VoN * VoN);
+    float saSq = eta * eta * mad(-VoN, VoN, 1.0f);
     float ca = ml_sqrt01(1.0f - saSq);
-    float Rs = (eta * VoN - ca) * ml_positive_rcp(eta * VoN + ca);
-    float Rp = (eta * ca - VoN) * ml_positive_rcp(eta * ca + VoN);
-    return 0.5f * (Rs * Rs + Rp * Rp);
+    float Rs = mad(eta, VoN, -ca) * ml_positive_rcp(mad(eta, VoN, ca));
+    float Rp = mad(eta, ca, -VoN) * ml_positive_rcp(mad(eta, ca, VoN));
+    return 0.5f * mad(Rp, Rp, Rs * Rs);
 }
 PT_DEV float ml_diffuse_burley(float roughness, float NoL, float NoV, float VoH)
 {
-    float f = 2.0f * VoH * VoH * roughness - 0.5f;
-    float FdV = f * ml_pow5_01(1.0f - NoV) + 1.0f;
-    float FdL = f * ml_pow5_01(1.0f - NoL) + 1.0f;
+    float f = mad(2.0f * VoH * VoH, roughness, -0.5f);
+    float FdV = mad(f, ml_pow5_01(1.0f - NoV), 1.0f);
+    float FdL = mad(f, ml_pow5_01(1.0f - NoL), 1.0f);
     return PT_DIV_CONST(FdV * FdL, kPi);
 }
 PT_DEV v3 ml_env_term_rtg(v3 F0, float NoV, float roughness)     // RTG ch.32 rational fit
@@ -247,9 +248,9 @@ PT_DEV v3 ml_vndf_get_ray(float u0, float u1, float roughness, v3 Vl)     // Dup
     float m = roughness * roughness;
     v3 Vh = normalize(V3(m * Vl.x, m * Vl.y, Vl.z));
     float s, c; sincos_2pi(u0, s, c);
-    float z = (1.0f - u1) * (1.0f + Vh.z) - Vh.z;
-    float sinT = ml_sqrt01(1.0f - z * z);
-    v3 h = V3(sinT * c + Vh.x, sinT * s + Vh.y, z + Vh.z);
+    float z = mad(1.0f - u1, 1.0f + Vh.z, -Vh.z);
+    float sinT = ml_sqrt01(mad(-z, z, 1.0f));
+    v3 h = V3(mad(sinT, c, Vh.x), mad(sinT, s, Vh.y), z + Vh.z);
     return normalize(V3(m * h.x, m * h.y, fmaxf(h.z, 0.0f)));
 }
 PT_DEV float ml_vndf_pdf(v3 Vl, float NoH, float roughness)
@@ -257,8 +258,8 @@ PT_DEV float ml_vndf_pdf(v3 Vl, float NoH, float roughness)
     float m = roughness * roughness;
     float D = ml_distribution_ggx(roughness, NoH);
     float ax = m * Vl.x, ay = m * Vl.y;
-    float len2 = ax * ax + ay * ay;
-    float t = sqrtf(len2 + Vl.z * Vl.z);
+    float len2 = mad(ay, ay, ax * ax);
+    float t = sqrtf(mad(Vl.z, Vl.z, len2));
     if (Vl.z >= 0.0f) return D / (2.0f * (Vl.z + t));
     return D * (t - Vl.z) / (2.0f * len2);
 }
@@ -300,7 +301,7 @@ struct BSDFSample {                           // BxDF.hlsli:36-44
         if (!isFrontFace) { IORi = IOR; IORo = 1.0f; }
         float r = (IORi - IORo) / (IORi + IORo);
         float r2 = r * r;
-        F0 = V3(r2 + metallic * (baseColor.x - r2), r2 + metallic * (baseColor.y - r2), r2 + metallic * (baseColor.z - r2));
+        F0 = V3(mad(metallic, baseColor.x - r2, r2), mad(metallic, baseColor.y - r2, r2), mad(metallic, baseColor.z - r2, r2));
         Transmission = transmission;
     }
 
@@ -328,14 +329,14 @@ struct BSDFSample {                           // BxDF.hlsli:36-44
         w[LOBE_TRANSMISSION] = tw;
     }
 
-    PT_DEV static v3 reflect(v3 i, v3 n) { float d = dot(n, i); return i - n * (2.0f * d); }
+    PT_DEV static v3 reflect(v3 i, v3 n) { float d = dot(n, i); return madd(n, -(2.0f * d), i); }
     PT_DEV static v3 refract(v3 i, v3 n, float eta)
     {
         float d = dot(n, i);
-        float k = 1.0f - eta * eta * (1.0f - d * d);
+        float k = mad(-(eta * eta), mad(-d, d, 1.0f), 1.0f);
         if (k < 0.0f) return V3(0.0f, 0.0f, 0.0f);
-        float s = eta * d + sqrtf(k);
-        return i * eta - n * s;
+        float s = mad(eta, d, sqrtf(k));
+        return madd(n, -s, i * eta);
     }
 
     // FindLobe :198-212 + Sample :214-226 (+ :81-86, :110-118, :148-168)

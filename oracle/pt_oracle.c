@@ -228,7 +228,7 @@ static f3 ml_cosine_get_ray(float u0, float u1)
 {
     float s, c; or_sincos_2pi(u0, &s, &c);
     float cosT = ml_sqrt01(u1);
-    float sinT = ml_sqrt01(1.0f - cosT * cosT);
+    float sinT = ml_sqrt01(mad(-cosT, cosT, 1.0f));
     return F3(sinT * c, sinT * s, cosT);
 }
 static inline float ml_cosine_pdf(float NoL) { return NoL / 3.14159265358979323846f; }
@@ -238,7 +238,7 @@ static float ml_distribution_ggx(float roughness, float NoH)
 {
     float m = roughness * roughness;
     float m2 = m * m;
-    float t = (NoH * m2 - NoH) * NoH + 1.0f;
+    float t = mad(mad(NoH, m2, -NoH), NoH, 1.0f);
     float a = m / t;
     return a * a / 3.14159265358979323846f;
 }
@@ -247,31 +247,31 @@ static float ml_geometry_term_mod(float roughness, float NoL, float NoV)
 {
     float m = roughness * roughness;
     float m2 = m * m;
-    float a = NoL * ml_sqrt01((NoV - m2 * NoV) * NoV + m2);
-    float b = NoV * ml_sqrt01((NoL - m2 * NoL) * NoL + m2);
+    float a = NoL * ml_sqrt01(mad(mad(-m2, NoV, NoV), NoV, m2));
+    float b = NoV * ml_sqrt01(mad(mad(-m2, NoL, NoL), NoL, m2));
     return 0.5f * ml_positive_rcp(a + b);
 }
 /* BRDF::FresnelTerm: Schlick */
 static f3 ml_fresnel_schlick(f3 F0, float VoH)
 {
     float f = ml_pow5_01(1.0f - VoH);
-    return F3(F0.x + (1.0f - F0.x) * f, F0.y + (1.0f - F0.y) * f, F0.z + (1.0f - F0.z) * f);
+    return F3(mad(1.0f - F0.x, f, F0.x), mad(1.0f - F0.y, f, F0.y), mad(1.0f - F0.z, f, F0.z));
 }
 /* BRDF::FresnelTerm_Dielectric: exact unpolarised Fresnel, eta = n_i / n_t */
 static float ml_fresnel_dielectric(float eta, float VoN)
 {
-    float saSq = eta * eta * (1.0f - VoN * VoN);
+    float saSq = eta * eta * mad(-VoN, VoN, 1.0f);
     float ca = ml_sqrt01(1.0f - saSq);
-    float Rs = (eta * VoN - ca) * ml_positive_rcp(eta * VoN + ca);
-    float Rp = (eta * ca - VoN) * ml_positive_rcp(eta * ca + VoN);
-    return 0.5f * (Rs * Rs + Rp * Rp);
+    float Rs = mad(eta, VoN, -ca) * ml_positive_rcp(mad(eta, VoN, ca));
+    float Rp = mad(eta, ca, -VoN) * ml_positive_rcp(mad(eta, ca, VoN));
+    return 0.5f * mad(Rp, Rp, Rs * Rs);
 }
 /* BRDF::DiffuseTerm: Burley / Disney */
 static float ml_diffuse_burley(float roughness, float NoL, float NoV, float VoH)
 {
-    float f = 2.0f * VoH * VoH * roughness - 0.5f;
-    float FdV = f * ml_pow5_01(1.0f - NoV) + 1.0f;
-    float FdL = f * ml_pow5_01(1.0f - NoL) + 1.0f;
+    float f = mad(2.0f * VoH * VoH, roughness, -0.5f);
+    float FdV = mad(f, ml_pow5_01(1.0f - NoV), 1.0f);
+    float FdL = mad(f, ml_pow5_01(1.0f - NoL), 1.0f);
     return FdV * FdL / 3.14159265358979323846f;
 }
 /* BRDF::EnvironmentTerm_Rtg: rational fit of the split-sum integral, Ray Tracing Gems ch. 32 */
@@ -308,9 +308,9 @@ static f3 ml_vndf_get_ray(float u0, float u1, float roughness, f3 Vl)
     float m = roughness * roughness;
     f3 Vh = normalize3(F3(m * Vl.x, m * Vl.y, Vl.z));
     float s, c; or_sincos_2pi(u0, &s, &c);
-    float z = (1.0f - u1) * (1.0f + Vh.z) - Vh.z;
-    float sinT = ml_sqrt01(1.0f - z * z);
-    f3 h = F3(sinT * c + Vh.x, sinT * s + Vh.y, z + Vh.z);
+    float z = mad(1.0f - u1, 1.0f + Vh.z, -Vh.z);
+    float sinT = ml_sqrt01(mad(-z, z, 1.0f));
+    f3 h = F3(mad(sinT, c, Vh.x), mad(sinT, s, Vh.y), z + Vh.z);
     return normalize3(F3(m * h.x, m * h.y, fmaxf(h.z, 0.0f)));
 }
 /* ImportanceSampling::VNDF::GetPDF(Vlocal, NoH, roughness): pdf of L = G1(V) D(H) / (4 NoV)
@@ -320,8 +320,8 @@ static float ml_vndf_pdf(f3 Vl, float NoH, float roughness)
     float m = roughness * roughness;
     float D = ml_distribution_ggx(roughness, NoH);
     float ax = m * Vl.x, ay = m * Vl.y;
-    float len2 = ax * ax + ay * ay;
-    float t = sqrtf(len2 + Vl.z * Vl.z);
+    float len2 = mad(ay, ay, ax * ax);
+    float t = sqrtf(mad(Vl.z, Vl.z, len2));
     if (Vl.z >= 0.0f) return D / (2.0f * (Vl.z + t));
     return D * (t - Vl.z) / (2.0f * len2);
 }
@@ -368,8 +368,8 @@ static void bsdf_init(BSDFSample* b, f3 baseColor, float metallic, float roughne
     if (!isFrontFace) { b->IORi = IOR; b->IORo = 1.0f; }
     float r = (b->IORi - b->IORo) / (b->IORi + b->IORo);
     float r2 = r * r;                                   /* pow(x, 2) */
-    b->F0 = F3(r2 + metallic * (baseColor.x - r2), r2 + metallic * (baseColor.y - r2),
-               r2 + metallic * (baseColor.z - r2));     /* lerp(a,b,t) = a + t*(b-a) */
+    b->F0 = F3(mad(metallic, baseColor.x - r2, r2), mad(metallic, baseColor.y - r2, r2),
+               mad(metallic, baseColor.z - r2, r2));    /* lerp(a,b,t) = fma(t, b-a, a) */
     b->Transmission = transmission;
 }
 
@@ -409,14 +409,14 @@ static int find_lobe(const float w[3], float random)
     return lobe;
 }
 
-static inline f3 reflect3(f3 i, f3 n) { float d = dot3(n, i); return sub3(i, scl3(n, 2.0f * d)); }
+static inline f3 reflect3(f3 i, f3 n) { float d = dot3(n, i); return madd3(n, -(2.0f * d), i); }
 static inline f3 refract3(f3 i, f3 n, float eta)
 {
     float d = dot3(n, i);
-    float k = 1.0f - eta * eta * (1.0f - d * d);
+    float k = mad(-(eta * eta), mad(-d, d, 1.0f), 1.0f);
     if (k < 0.0f) return F3(0.0f, 0.0f, 0.0f);
-    float s = eta * d + sqrtf(k);
-    return sub3(scl3(i, eta), scl3(n, s));
+    float s = mad(eta, d, sqrtf(k));
+    return madd3(n, -s, scl3(i, eta));
 }
 
 /* BxDF.hlsli:81-86, 110-118, 148-168, 214-226 */
@@ -1542,7 +1542,7 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                     if (!sample && bounce == 1) { isDiffuse = lobe == LOBE_DIFFUSE; hitDistance = hit.Distance; }   /* :235-239 */
                     if (!isHit) {                                                       /* :241-259 */
                         f3 env = environment_light_color(s, sd, ray.Direction);
-                        sampleRadiance = add3(sampleRadiance, mul3(throughput, env));
+                        sampleRadiance = F3(mad(throughput.x, env.x, sampleRadiance.x), mad(throughput.y, env.y, sampleRadiance.y), mad(throughput.z, env.z, sampleRadiance.z));
                         break;
                     }
                     if (bounce) {                                                       /* :293-304 */
@@ -1552,7 +1552,7 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                         emission = material_emission(m);
                         bsdf_init(&bs, ld3(m->BaseColor), m->Metallic, m->Roughness, m->IOR, m->Transmission, hit.IsFrontFace);
                     }
-                    sampleRadiance = add3(sampleRadiance, mul3(throughput, emission));  /* :320 */
+                    sampleRadiance = F3(mad(throughput.x, emission.x, sampleRadiance.x), mad(throughput.y, emission.y, sampleRadiance.y), mad(throughput.z, emission.z, sampleRadiance.z));  /* :320 */
                     SurfaceVectors sv = surface_vectors(hit.IsFrontFace, hit.GeometricNormal, hit.ShadingNormal);
                     f3 V = neg3(ray.Direction);
                     float w[3];
