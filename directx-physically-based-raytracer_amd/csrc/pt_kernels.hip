@@ -824,6 +824,14 @@ constexpr uint32_t kStreamRefillMin = PT_STREAM_REFILL; // idle lanes worth a re
 constexpr uint32_t kStreamMinLanes = PT_STREAM_MINLANES;   // a section (node visit / triangle test / instance entry) runs in a step when at least this many lanes ...
 constexpr uint32_t kStreamShareShift = PT_STREAM_SHARE;    // ... and at least (lanes of the busiest section >> this) wait for it; the busiest always runs
 constexpr uint32_t kStreamLdsStack = (uint32_t)kStreamStackLds * 256u * 8u;
+#ifndef PT_STREAM_TRIPAIRS
+#define PT_STREAM_TRIPAIRS 1
+#endif
+constexpr bool kStreamTriPairs = PT_STREAM_TRIPAIRS != 0;   // two triangles of a leaf group per step
+#ifndef PT_STREAM_MERGE
+#define PT_STREAM_MERGE 0
+#endif
+constexpr bool kStreamMerge = PT_STREAM_MERGE != 0;         // a node visit and a triangle test in one step (measured: no gain over pairs alone, C3 2272 vs 2286, C5 1953 vs 1950: off)
 
 // The traversal half alone, same streaming walk: hits go to the queue's hit records (16 B per ray through HBM, nothing next to
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
@@ -918,56 +926,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 if (exhausted) { prof[8]++; prof[9] += nLive; }
             }
 #endif
-            // what this lane does: 0 nothing, 1 node, 2 triangle, 4 instance entry
-            uint32_t act = 0, addr = 0, item = 0;
-            if (leaf && (top ? doEnter : doTri)) {
-                item = T.x + (uint32_t)__builtin_ctz(T.y);
-                T.y &= T.y - 1u;
-                if (top) { act = 4u; addr = bv.leafInstOff16 + item * kInst16; }
-                else { act = 2u; addr = triBase16 + item * kTri16; }
-            } else if (wantNode && doNode) {
-                if (T.y) { stack.push(T); T.y = 0u; }                     // postpone the leaf group
-                act = 1u;
+            // What this lane does in the step. The walk is bound by the latency of its steps (decide -> fetch -> test -> pop is one
+            // dependent chain), not by the instructions in them, so a triangle step takes two triangles of the leaf group at once (the second
+            // one's record goes where a node's last units would): C3 +4.6 %, C5 +2.6 %. kStreamMerge additionally lets a node visit and a
+            // triangle test share a step (triangle first: a hit shortens the ray before the node's boxes are tested).
+            bool aN = false, aT = false, aT2 = false, aE = false;
+            uint32_t addrN = 0, addrT = 0, addrT2 = 0, item = 0, item2 = 0;
+            if (leaf && top) {
+                if (doEnter) { aE = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrN = bv.leafInstOff16 + item * kInst16; }
+            } else if (leaf && doTri) {
+                aT = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrT = triBase16 + item * kTri16;
+            }
+            if (!aE && wantNode && doNode && (kStreamMerge || !aT)) {
+                if (T.y) { stack.push(T); T.y = 0u; }                     // postpone (the rest of) the leaf group: the visit brings a new one
+                aN = true;
                 const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
                 G.y &= ~(1u << bit);
                 if (G.y > 0x00FFFFFFu) stack.push(G);
                 const uint32_t slot = (bit - 24u) ^ (br.octinv4 & 7u);
-                addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
+                addrN = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
             }
+            if (kStreamTriPairs && aT && !aN && T.y) { aT2 = true; item2 = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrT2 = triBase16 + item2 * kTri16; }
             // ---- all loads of the step (a wave-cooperative gather through LDS -- neighbouring lanes fetching neighbouring 16-byte
-            // units of one record -- was tried here and lost 30 %: the walk is bound by VALU issue, not by the vector cache)
-            // (registers of lanes that do not load stay undefined and are not read: no zero fill; one address, immediate offsets)
-            f4v L0 = undefined_f4v(), L1 = undefined_f4v(), L2 = undefined_f4v(), L3 = undefined_f4v(), L4 = undefined_f4v(), L5 = undefined_f4v();
-            const f4v* rec = blob.p + addr;
-            if (act != 0u) { L0 = rec[0]; L1 = rec[1]; L2 = rec[2]; }
-            if (act == 1u || act == 4u) { L3 = rec[3]; L4 = rec[4]; }
-            if (act == 4u) L5 = rec[5];
-            // ---- sections
-            if (act == 1u) {
-                if (STATS) st.nodes++;
-                const uint32_t hits = wide_node_hits(L0, L1, L2, L3, L4, br, tmin, h.t);
-                G = make_uint2(__float_as_uint(L1.x), (hits & 0xFF000000u) | (__float_as_uint(L0.w) >> 24));
-                T = make_uint2(__float_as_uint(L1.y), hits & 0x00FFFFFFu);
+            // units of one record -- was tried here and lost 30 %). Registers of lanes that do not load stay undefined and are not
+            // read: no zero fill; one address per record, immediate offsets. A0..A4: node, or instance record, or (A2..A4) the second
+            // triangle; B0..B2: the triangle, or (B0) the last unit of an instance record.
+            f4v A0 = undefined_f4v(), A1 = undefined_f4v(), A2 = undefined_f4v(), A3 = undefined_f4v(), A4 = undefined_f4v();
+            f4v B0 = undefined_f4v(), B1 = undefined_f4v(), B2 = undefined_f4v();
+            {
+                const f4v* recN = blob.p + addrN; const f4v* recT = blob.p + addrT; const f4v* recT2 = blob.p + addrT2;
+                if (aN || aE) { A0 = recN[0]; A1 = recN[1]; A2 = recN[2]; A3 = recN[3]; A4 = recN[4]; }
+                if (aE) B0 = recN[5];
+                if (aT) { B0 = recT[0]; B1 = recT[1]; B2 = recT[2]; }
+                if (aT2) { A2 = recT2[0]; A3 = recT2[1]; A4 = recT2[2]; }
             }
-            if (act == 2u) {
+            // ---- sections
+            if (aT) {
                 if (STATS) st.tris++;
                 float t, u, v;
-                if (tri_test(rs, br.o, V3(L0.x, L0.y, L0.z), V3(L1.x, L1.y, L1.z), V3(L2.x, L2.y, L2.z), t, u, v))
-                    commit_candidate(ac, __float_as_uint(L2.w), h, tmin, t, u, v, curInst, __float_as_uint(L0.w), __float_as_uint(L1.w), item);
+                if (tri_test(rs, br.o, V3(B0.x, B0.y, B0.z), V3(B1.x, B1.y, B1.z), V3(B2.x, B2.y, B2.z), t, u, v))
+                    commit_candidate(ac, __float_as_uint(B2.w), h, tmin, t, u, v, curInst, __float_as_uint(B0.w), __float_as_uint(B1.w), item);
             }
-            if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
-                const uint32_t ntri = __float_as_uint(L5.y);
-                if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
-                    const v3 ro = V3(sop3t(L0.x, wo.x, L0.y, wo.y, L0.z, wo.z, L0.w), sop3t(L1.x, wo.x, L1.y, wo.y, L1.z, wo.z, L1.w), sop3t(L2.x, wo.x, L2.y, wo.y, L2.z, wo.z, L2.w));
-                    const v3 rd = V3(sop3(L0.x, wd.x, L0.y, wd.y, L0.z, wd.z), sop3(L1.x, wd.x, L1.y, wd.y, L1.z, wd.z), sop3(L2.x, wd.x, L2.y, wd.y, L2.z, wd.z));
+            if (aT2) {
+                if (STATS) st.tris++;
+                float t, u, v;
+                if (tri_test(rs, br.o, V3(A2.x, A2.y, A2.z), V3(A3.x, A3.y, A3.z), V3(A4.x, A4.y, A4.z), t, u, v))
+                    commit_candidate(ac, __float_as_uint(A4.w), h, tmin, t, u, v, curInst, __float_as_uint(A2.w), __float_as_uint(A3.w), item2);
+            }
+            if (aN) {
+                if (STATS) st.nodes++;
+                const uint32_t hits = wide_node_hits(A0, A1, A2, A3, A4, br, tmin, h.t);
+                G = make_uint2(__float_as_uint(A1.x), (hits & 0xFF000000u) | (__float_as_uint(A0.w) >> 24));
+                T = make_uint2(__float_as_uint(A1.y), hits & 0x00FFFFFFu);
+            }
+            if (aE) {                                                    // enter the instance (or skip it: hidden / empty)
+                const uint32_t ntri = __float_as_uint(B0.y);
+                if ((__float_as_uint(B0.x) & 0xFFu) && ntri != 0u) {
+                    const v3 ro = V3(sop3t(A0.x, wo.x, A0.y, wo.y, A0.z, wo.z, A0.w), sop3t(A1.x, wo.x, A1.y, wo.y, A1.z, wo.z, A1.w), sop3t(A2.x, wo.x, A2.y, wo.y, A2.z, wo.z, A2.w));
+                    const v3 rd = V3(sop3(A0.x, wd.x, A0.y, wd.y, A0.z, wd.z), sop3(A1.x, wd.x, A1.y, wd.y, A1.z, wd.z), sop3(A2.x, wd.x, A2.y, wd.y, A2.z, wd.z));
                     rs = ray_setup(rd);
                     br = box_ray(ro, rd);
-                    nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;
-                    triBase16 = bv.triOff16 + __float_as_uint(L4.w) * kTri16;
+                    nodeBase16 = bv.nodeOff16 + __float_as_uint(A3.w) * kNode16;
+                    triBase16 = bv.triOff16 + __float_as_uint(A4.w) * kTri16;
                     stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
                     const bool single = blas_single_leaf(ntri);
                     G = root_node_group(single); T = root_tri_group(single, ntri);
-                    curInst = __float_as_uint(L5.w);
+                    curInst = __float_as_uint(B0.w);
                 }
             }
             // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
