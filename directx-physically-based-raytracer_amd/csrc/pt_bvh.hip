@@ -225,10 +225,11 @@ struct DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[2]
 static_assert(sizeof(DpNode) == 40, "layout");
 constexpr float kCostNode = 1.0f;
 #ifndef PT_COST_TRI
-#define PT_COST_TRI 0.3f
+#define PT_COST_TRI 0.6f
 #define PT_COST_INST 1.0f
 #endif
-constexpr float kCostTriangle = PT_COST_TRI;         // a triangle test against a node visit (measured instruction counts: ~80 against ~245)
+constexpr float kCostTriangle = PT_COST_TRI;         // a triangle test against a node visit. By instruction counts (~97 against ~225) 0.4; measured 0.3 -> 0.6: C3 +3 %, C5 +3 %
+                                                     // (a triangle is also a step of the walk, and steps are what the streaming traversal pays for), flat from 0.6 to 0.9
 constexpr float kCostInstance = PT_COST_INST;        // entering an instance: look-up, ray transform, BLAS root
 
 __device__ __forceinline__ float half_area(float4 lo, float4 hi)
