@@ -396,6 +396,16 @@ PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const A
             } else {
                 const uint32_t ta = triBase16 + i * kTri16;
                 const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+                // closest hit: a second triangle of the group is fetched with the first (one latency for both, as in the streaming walk)
+                const bool two = !ANYHIT && T.y != 0u;
+                uint32_t i2 = 0;
+                f4v qa = pa, qb = pb, qc = pc;
+                if (two) {
+                    i2 = T.x + (uint32_t)__builtin_ctz(T.y);
+                    T.y &= T.y - 1u;
+                    const uint32_t tb = triBase16 + i2 * kTri16;
+                    qa = blob.ld(tb); qb = blob.ld(tb + 1); qc = blob.ld(tb + 2);
+                }
                 if (STATS) stats->tris++;
                 PT_LOG(2u, curInst, i);
                 float t, u, v;
@@ -412,6 +422,12 @@ PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const A
                             break;
                         }
                     }
+                }
+                if (two) {
+                    if (STATS) stats->tris++;
+                    PT_LOG(2u, curInst, i2);
+                    if (tri_test(rs, ro, V3(qa.x, qa.y, qa.z), V3(qb.x, qb.y, qb.z), V3(qc.x, qc.y, qc.z), t, u, v))
+                        commit_candidate(ac, __float_as_uint(qc.w), h, tmin, t, u, v, curInst, __float_as_uint(qa.w), __float_as_uint(qb.w), i2);
                 }
             }
         } else if (G.y > 0x00FFFFFFu) {
