@@ -337,7 +337,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
     }
     const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
-    const size_t total = instBytes + nodeBytes + triBytes + instBytes;
+    const size_t total = instBytes + nodeBytes + triBytes + instBytes + instBytes;   // ... | leaf-order records | entry records (same size)
     API_ARG(&c, total / 16 < 0xFFFFFFFFull, "scene too large for 32-bit blob addressing");
 
     // ---- capacities: everything is grow-only, so the rebuild of an unchanged scene layout (a dynamic frame) allocates nothing and
@@ -395,7 +395,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.stream);
     if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
     if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.blasBounds, dTable, count, (InstanceT*)blob, c.tlas.order,
-                                                 (InstanceT*)(blob + instBytes + nodeBytes + triBytes), dJobs, (uint32_t)jobs.size(), c.stream);
+                                                 (InstanceT*)(blob + instBytes + nodeBytes + triBytes), dJobs, (uint32_t)jobs.size(),
+                                                 (const f4v*)(blob + instBytes), (f4v*)(blob + instBytes + nodeBytes + triBytes + instBytes), c.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipEventRecord(c.tlasHeaderEvent, c.stream);
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
@@ -403,6 +404,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     c.blob.base = (const f4v*)blob;
     c.blob.instOff16 = 0; c.blob.nodeOff16 = (uint32_t)(instBytes / 16); c.blob.triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
     c.blob.leafInstOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
+    c.blob.enterOff16 = (uint32_t)((instBytes + nodeBytes + triBytes + instBytes) / 16);
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;

@@ -824,12 +824,31 @@ hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* t
     return hipGetLastError();
 }
 
+// Entry records of the streaming traversal, in TLAS leaf order: what entering an instance needs, in one fetch -- worldToObject (3
+// units), node base | triangle base | triangle count (24 bits) + mask | InstanceIndex (1 unit), and a copy of the BLAS's root node
+// (5 units), so that the step that enters the instance also visits its root. Runs after k_blob_copy (reads the blob's node section).
+__global__ void k_blob_enter_records(const InstanceT* __restrict__ api, const uint32_t* __restrict__ order, uint32_t n,
+                                     const uint4* __restrict__ blobNodes, uint4* __restrict__ out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                 // one 16-byte unit per thread
+    if (t >= n * kInst16) return;
+    const uint32_t p = t / kInst16, part = t - p * kInst16;
+    const InstanceT* src = &api[order[p]];
+    uint4 v;
+    if (part < 3u) v = ((const uint4*)src)[part];
+    else if (part == 3u) v = make_uint4(src->nodeBase, src->triBase, (src->triCount < 0xFFFFFFu ? src->triCount : 0xFFFFFFu) | (src->mask << 24), src->instanceIndex);
+    else v = blobNodes[(size_t)src->nodeBase * kNode16 + (part - 4u)];
+    out[t] = v;
+}
+
 hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
-                                const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs, hipStream_t stream)
+                                const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs,
+                                const f4v* blobNodes, f4v* outEnter, hipStream_t stream)
 {
     if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, bounds, table, n, outInst);
     if (n) k_blob_leaf_instances<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, outLeafInst);
     if (njobs) k_blob_copy<<<dim3(64, njobs < 1024 ? njobs : 1024), 256, 0, stream>>>(jobs, njobs);
+    if (n) k_blob_enter_records<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, (const uint4*)blobNodes, (uint4*)outEnter);
     return hipGetLastError();
 }
 

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             bool aN = false, aT = false, aT2 = false, aE = false;
             uint32_t addrN = 0, addrT = 0, addrT2 = 0, item = 0, item2 = 0;
             if (leaf && top) {
-                if (doEnter) { aE = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrN = bv.leafInstOff16 + item * kInst16; }
+                if (doEnter) { aE = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrN = bv.enterOff16 + item * kInst16; }
             } else if (leaf && doTri) {
                 aT = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrT = triBase16 + item * kTri16;
             }
@@ -962,11 +962,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             // read: no zero fill; one address per record, immediate offsets. A0..A4: node, or instance record, or (A2..A4) the second
             // triangle; B0..B2: the triangle, or (B0) the last unit of an instance record.
             f4v A0 = undefined_f4v(), A1 = undefined_f4v(), A2 = undefined_f4v(), A3 = undefined_f4v(), A4 = undefined_f4v();
-            f4v B0 = undefined_f4v(), B1 = undefined_f4v(), B2 = undefined_f4v();
+            f4v B0 = undefined_f4v(), B1 = undefined_f4v(), B2 = undefined_f4v(), C0 = undefined_f4v();
             {
                 const f4v* recN = blob.p + addrN; const f4v* recT = blob.p + addrT; const f4v* recT2 = blob.p + addrT2;
-                if (aN || aE) { A0 = recN[0]; A1 = recN[1]; A2 = recN[2]; A3 = recN[3]; A4 = recN[4]; }
-                if (aE) B0 = recN[5];
+                if (aN) { A0 = recN[0]; A1 = recN[1]; A2 = recN[2]; A3 = recN[3]; A4 = recN[4]; }
+                if (aE) { B0 = recN[0]; B1 = recN[1]; B2 = recN[2]; C0 = recN[3]; A0 = recN[4]; A1 = recN[5]; A2 = recN[6]; A3 = recN[7]; A4 = recN[8]; }   // entry record: transform | bases | root node
                 if (aT) { B0 = recT[0]; B1 = recT[1]; B2 = recT[2]; }
                 if (aT2) { A2 = recT2[0]; A3 = recT2[1]; A4 = recT2[2]; }
             }
@@ -989,19 +989,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
                 G = make_uint2(__float_as_uint(A1.x), (hits & 0xFF000000u) | (__float_as_uint(A0.w) >> 24));
                 T = make_uint2(__float_as_uint(A1.y), hits & 0x00FFFFFFu);
             }
-            if (aE) {                                                    // enter the instance (or skip it: hidden / empty)
-                const uint32_t ntri = __float_as_uint(B0.y);
-                if ((__float_as_uint(B0.x) & 0xFFu) && ntri != 0u) {
-                    const v3 ro = V3(sop3t(A0.x, wo.x, A0.y, wo.y, A0.z, wo.z, A0.w), sop3t(A1.x, wo.x, A1.y, wo.y, A1.z, wo.z, A1.w), sop3t(A2.x, wo.x, A2.y, wo.y, A2.z, wo.z, A2.w));
-                    const v3 rd = V3(sop3(A0.x, wd.x, A0.y, wd.y, A0.z, wd.z), sop3(A1.x, wd.x, A1.y, wd.y, A1.z, wd.z), sop3(A2.x, wd.x, A2.y, wd.y, A2.z, wd.z));
+            if (aE) {                                                    // enter the instance (or skip it: hidden / empty) and visit the root of its BLAS
+                const uint32_t cm = __float_as_uint(C0.z), ntri = cm & 0x00FFFFFFu;
+                if ((cm >> 24) && ntri != 0u) {
+                    const v3 ro = V3(sop3t(B0.x, wo.x, B0.y, wo.y, B0.z, wo.z, B0.w), sop3t(B1.x, wo.x, B1.y, wo.y, B1.z, wo.z, B1.w), sop3t(B2.x, wo.x, B2.y, wo.y, B2.z, wo.z, B2.w));
+                    const v3 rd = V3(sop3(B0.x, wd.x, B0.y, wd.y, B0.z, wd.z), sop3(B1.x, wd.x, B1.y, wd.y, B1.z, wd.z), sop3(B2.x, wd.x, B2.y, wd.y, B2.z, wd.z));
                     rs = ray_setup(rd);
                     br = box_ray(ro, rd);
-                    nodeBase16 = bv.nodeOff16 + __float_as_uint(A3.w) * kNode16;
-                    triBase16 = bv.triOff16 + __float_as_uint(A4.w) * kTri16;
+                    nodeBase16 = bv.nodeOff16 + __float_as_uint(C0.x) * kNode16;
+                    triBase16 = bv.triOff16 + __float_as_uint(C0.y) * kTri16;
                     stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
-                    const bool single = blas_single_leaf(ntri);
-                    G = root_node_group(single); T = root_tri_group(single, ntri);
-                    curInst = __float_as_uint(B0.w);
+                    curInst = __float_as_uint(C0.w);
+                    if (blas_single_leaf(ntri)) { G = root_node_group(true); T = root_tri_group(true, ntri); }
+                    else {                                               // the root node came with the record: one step less per instance
+                        if (STATS) st.nodes++;
+                        const uint32_t hits = wide_node_hits(A0, A1, A2, A3, A4, br, tmin, h.t);
+                        G = make_uint2(__float_as_uint(A1.x), (hits & 0xFF000000u) | (__float_as_uint(A0.w) >> 24));
+                        T = make_uint2(__float_as_uint(A1.y), hits & 0x00FFFFFFu);
+                    }
                 }
             }
             // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done

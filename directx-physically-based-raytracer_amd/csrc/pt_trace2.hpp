@@ -11,7 +11,7 @@
 //
 // The blob is ONE contiguous allocation addressed in 16-byte units so that the identical code reads it from
 // HBM/L2 (large scenes) or from LDS (scenes that fit: the block stages the blob once, "LDS-staged node /
-// triangle packets"):   [ InstanceT x instCount | WideNode x nodeCount | TriPacket x triCount | InstanceT x instCount in TLAS leaf order ]
+// triangle packets"):   [ InstanceT x instCount | WideNode x nodeCount | TriPacket x triCount | InstanceT x instCount in TLAS leaf order | entry records ]
 // TLAS nodes come first in the node array (root = 0); a BLAS's nodes / packets are contiguous at nodeBase / triBase. Child
 // and triangle references of a node stay relative to their own tree. The TLAS's "triangles" are the instance records of the last
 // section: the same records as the first, in the order of the TLAS leaves, so that entering an instance is one fetch.
@@ -33,6 +33,7 @@ static_assert(sizeof(InstanceT) == 144, "layout");
 struct BlobView {
     const f4v* base;                   // device pointer to the blob
     uint32_t instOff16, nodeOff16, triOff16, leafInstOff16;   // section starts in 16-byte units
+    uint32_t enterOff16;               // entry records (9 units per instance, TLAS leaf order): worldToObject | bases, count, mask, index | the BLAS's root node
     uint32_t instCount, nodeCount, triCount;
     uint32_t bytes;                    // whole blob
 };
