@@ -828,6 +828,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #define PT_STREAM_MINLANES 8
 #define PT_STREAM_SHARE 1
 #endif
+#ifndef PT_STREAM_GRID_SHARED
+#define PT_STREAM_GRID_SHARED 512
+#define PT_STREAM_GRID_ALONE 1024
+#endif
 #ifndef PT_STREAM_STACK
 #define PT_STREAM_STACK 12
 #endif
@@ -1488,7 +1492,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
                 // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
                 // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-                const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? 512u : 1024u));
+                const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? (uint32_t)PT_STREAM_GRID_SHARED : (uint32_t)PT_STREAM_GRID_ALONE));
 #if PT_STREAM_COOP
                 #define PT_XS(S, W) k_extend_coop<S, W><<<sgrid, 256, kCoopLds, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
 #else
