@@ -80,6 +80,11 @@ def full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band, band_index, exac
     assert cp.StackOverflows == 0 and part["Radiance"].shape[0] == y1 - y0
     for k in GB_KEYS + ("Radiance",):
         assert np.array_equal(part[k], full[k][y0:y1]), f"{k}: the band rendered alone differs from the same rows of the full frame"
+    # pt_set_frames_in_flight(3) halves the grid of the streaming traversal (what bench.py runs with): the frame must not notice
+    gpu.set_frames_in_flight(3)
+    again, ca = gpu_render(ptamd, gpu, scene, gs, W, H)
+    gpu.set_frames_in_flight(1)
+    assert ca.SecondaryRays == cf.SecondaryRays and np.array_equal(again["RadianceF32"].view(np.uint32), full["RadianceF32"].view(np.uint32))
     ref_gb, ref_rays, ref_f32 = oracle_band(oracle, L, scene, gs, W, H, y0, y1)
     assert cp.PrimaryRays + cp.SecondaryRays == ref_rays                                       # identical path structure in the band
     check_band(part, ref_gb, ref_f32, exact)

@@ -391,6 +391,14 @@ def test_streaming_and_lockstep_schedules_agree(gpu, ptamd, pkg):
                 assert c.NodesVisited > 0 and c.TrianglesTested > 0
             results.append((ptamd.textures_to_numpy(r.textures)["RadianceF32"].view(np.uint32).copy(), c.SecondaryRays))
             gpu.set_debug_flags(0)
+        # pt_set_frames_in_flight only sizes the streaming traversal's grid (512 blocks instead of 1024): same image
+        gpu.set_frames_in_flight(3)
+        g = ptamd.Scene(gpu, scene)
+        r = ptamd.Renderer(gpu, g, W, H, with_f32=True)
+        gpu.reset_counters()
+        r.render(gs); gpu.sync()
+        results.append((ptamd.textures_to_numpy(r.textures)["RadianceF32"].view(np.uint32).copy(), gpu.counters().SecondaryRays))
+        gpu.set_frames_in_flight(1)
         for img, rays in results[1:]:
             assert rays == results[0][1] and np.array_equal(img, results[0][0])
 
