@@ -107,6 +107,23 @@ def check_blob(layout, buf, leaf_tris_rule):
         stats["blas_depth"] = max(stats["blas_depth"], depth); stats["blas_nodes"] += nn
     if len(inst):
         ilo, ihi = inst["boxLo"].astype(np.float64), inst["boxHi"].astype(np.float64)
+        # the world box of an instance (built from two levels of its BLAS's child boxes, pt_bvh.hip instance_world_box) must contain
+        # every triangle of the BLAS pushed through ObjectToWorld: checked on the vertices themselves, not on any box of them
+        worst = 0.0
+        for key in {(int(it["triBase"]), int(it["triCount"])) for it in inst if int(it["triCount"])}:
+            t = tris[key[0]:key[0] + key[1]]
+            v = np.concatenate([t["v0"], t["v1"], t["v2"]], 0).astype(np.float64)     # [3 tc, 3] object space
+            ids = np.nonzero((inst["triBase"] == key[0]) & (inst["triCount"] == key[1]))[0]
+            for c0 in range(0, len(ids), 512):
+                sel = ids[c0:c0 + 512]
+                M = inst["objectToWorld"][sel].astype(np.float64).reshape(-1, 3, 4)
+                w = np.einsum("iak,vk->iva", M[:, :, :3], v) + M[:, None, :, 3]            # [n, 3 tc, 3] world space
+                out = np.maximum(ilo[sel][:, None, :] - w, w - ihi[sel][:, None, :]).max((1, 2))
+                bad = np.nonzero(out > 0)[0]
+                worst = max(worst, float(out.max()))
+                for b in bad[:3]:
+                    problems.append(f"instance {int(sel[b])}: a vertex of its BLAS sticks out of its world box by {out[b]:.3e}")
+        stats["instance_box_slack_min"] = -worst
         if sorted(order.tolist()) != list(range(len(inst))):
             problems.append("instance order list is not a permutation")
 
