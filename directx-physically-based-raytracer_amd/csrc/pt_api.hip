@@ -394,7 +394,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     // ---- device side, all in stream order
     e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.stream);
     if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
-    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.blasBounds, dTable, count, (InstanceT*)blob, c.tlas.order,
+    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.tree.boxLo, c.tlas.tree.boxHi, dTable, count, (InstanceT*)blob, c.tlas.order,
                                                  (InstanceT*)(blob + instBytes + nodeBytes + triBytes), dJobs, (uint32_t)jobs.size(),
                                                  (const f4v*)(blob + instBytes), (f4v*)(blob + instBytes + nodeBytes + triBytes + instBytes), c.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);

@@ -181,6 +181,8 @@ __device__ __forceinline__ void grow_by_transformed_box(const float* M, const fl
     }
 }
 constexpr uint32_t kExactBoxTriangles = 1024;
+// The 64 lanes of a wave work on ONE instance: the triangles of the exact path are dealt to the lanes and the result reduced; the
+// node path is evaluated by every lane alike (a handful of boxes). All lanes return the same box.
 __device__ void instance_world_box(const InstanceRecord& ir, const float* b, float lo[3], float hi[3])
 {
     for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
@@ -190,7 +192,7 @@ __device__ void instance_world_box(const InstanceRecord& ir, const float* b, flo
     grow_by_transformed_box(M, rlo, rhi, lo, hi);
     float tlo[3] = { INFINITY, INFINITY, INFINITY }, thi[3] = { -INFINITY, -INFINITY, -INFINITY };
     if (ir.tris && ir.triCount <= kExactBoxTriangles) {                      // a small mesh: the vertices themselves (the tightest box there is)
-        for (uint32_t t = 0; t < ir.triCount; t++) {
+        for (uint32_t t = threadIdx.x & 63u; t < ir.triCount; t += 64u) {
             const TriPacket tp = ir.tris[t];
             const float4 v[3] = { tp.a, tp.b, tp.c };
             for (int k = 0; k < 3; k++)
@@ -199,6 +201,8 @@ __device__ void instance_world_box(const InstanceRecord& ir, const float* b, flo
                     tlo[a] = fminf(tlo[a], w); thi[a] = fmaxf(thi[a], w);
                 }
         }
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) { tlo[a] = fminf(tlo[a], __shfl_xor(tlo[a], off)); thi[a] = fmaxf(thi[a], __shfl_xor(thi[a], off)); }
         for (int a = 0; a < 3; a++) { lo[a] = fmaxf(lo[a], tlo[a]); hi[a] = fminf(hi[a], thi[a]); }
         return;
     }
@@ -222,21 +226,18 @@ __device__ void instance_world_box(const InstanceRecord& ir, const float* b, flo
     if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
 }
 
-// TLAS items: the world box of each instance
-__global__ void k_instance_boxes(const InstanceRecord* __restrict__ inst, const float* const* __restrict__ blasBounds, uint32_t n,
+// TLAS items: the world box of each instance, one wave per instance
+__global__ __launch_bounds__(256) void k_instance_boxes(const InstanceRecord* __restrict__ inst, const float* const* __restrict__ blasBounds, uint32_t n,
                                  float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ bounds)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    if (i < n) {
-        instance_world_box(inst[i], blasBounds[i], lo, hi);       // blasBounds: lo.xyz hi.xyz of the BLAS root
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;          // wave-uniform
+    if (i >= n) return;
+    float lo[3], hi[3];
+    instance_world_box(inst[i], blasBounds[i], lo, hi);                       // blasBounds: lo.xyz hi.xyz of the BLAS root
+    if ((threadIdx.x & 63u) == 0u) {
         boxLo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         boxHi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-    }
-    for (int a = 0; a < 3; a++) {
-        float l = lo[a], h = hi[a];
-        for (int off = 32; off > 0; off >>= 1) { l = fminf(l, __shfl_xor(l, off)); h = fmaxf(h, __shfl_xor(h, off)); }
-        if ((threadIdx.x & 63) == 0 && l <= h) { atomicMin(&bounds[a], f2ord(l)); atomicMax(&bounds[3 + a], f2ord(h)); }
+        for (int a = 0; a < 3; a++) if (lo[a] <= hi[a]) { atomicMin(&bounds[a], f2ord(lo[a])); atomicMax(&bounds[3 + a], f2ord(hi[a])); }
     }
 }
 
@@ -784,7 +785,7 @@ hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* cons
     out.instanceCount = n;
     if (n) {
         k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
-        k_instance_boxes<<<cdiv(n, 256), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
+        k_instance_boxes<<<cdiv(n, 4), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
     BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, false, out.nodes, out.rootBounds, stream));
     if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
@@ -831,17 +832,15 @@ __global__ void k_instance_records(const InstanceSource* __restrict__ src, const
     bounds[i] = b.rootBounds;
 }
 
-__global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const float* const* __restrict__ blasBounds,
+__global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const float4* __restrict__ itemLo, const float4* __restrict__ itemHi,
                                  const BlasEntry* __restrict__ table, uint32_t n, InstanceT* __restrict__ out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     InstanceT t;
     for (int k = 0; k < 12; k++) t.worldToObject[k] = inst[i].worldToObject[k];
-    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     const float* M = inst[i].objectToWorld;
-    instance_world_box(inst[i], blasBounds[i], lo, hi);
-    float4 l4 = make_float4(lo[0], lo[1], lo[2], 0.0f), h4 = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    float4 l4 = itemLo[i], h4 = itemHi[i];                                    // k_instance_boxes (the TLAS's items)
     pad_box(l4, h4);
     const BlasEntry e = table[inst[i].blasSlot];
     t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = e.nodeBase;
@@ -893,11 +892,11 @@ __global__ void k_blob_enter_records(const InstanceT* __restrict__ api, const ui
     out[t] = v;
 }
 
-hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const float4* itemLo, const float4* itemHi, const BlasEntry* table, uint32_t n, InstanceT* outInst,
                                 const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs,
                                 const f4v* blobNodes, f4v* outEnter, hipStream_t stream)
 {
-    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, bounds, table, n, outInst);
+    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, itemLo, itemHi, table, n, outInst);
     if (n) k_blob_leaf_instances<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, outLeafInst);
     if (njobs) k_blob_copy<<<dim3(64, njobs < 1024 ? njobs : 1024), 256, 0, stream>>>(jobs, njobs);
     if (n) k_blob_enter_records<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, (const uint4*)blobNodes, (uint4*)outEnter);

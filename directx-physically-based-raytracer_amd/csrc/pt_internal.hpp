@@ -147,7 +147,7 @@ hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
 hipError_t build_tlas_prepare(Tlas& out, uint32_t n);
 hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out);
 hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, hipStream_t stream);
-hipError_t launch_blob_assembly(const InstanceRecord* inst, const float* const* bounds, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const float4* itemLo, const float4* itemHi, const BlasEntry* table, uint32_t n, InstanceT* outInst,
                                 const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs,
                                 const f4v* blobNodes, f4v* outEnter, hipStream_t stream);
 __host__ __device__ void invert_3x4(const float m[12], float out[12]);

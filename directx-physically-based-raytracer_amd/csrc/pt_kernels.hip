@@ -1507,9 +1507,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         // fused rounds: everything except the validation / statistics variants, which keep the two-kernel form
         const uint32_t pairOnly = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
         if (!(c.debugFlags & pairOnly)) {
-            for (uint32_t r = 0; r <= rounds; r++) {
-                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
-                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
+            for (uint32_t r = 0; r <= rounds; r++) {                        // queues and counters of round r: in its argument block (launch_raytrace)
                 timing_begin(c, c.evRound, c.nRound);
                 #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(c.roundArgs + r)
                 #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)
