@@ -90,6 +90,9 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v)      // 21 bits -> ever
     return x;
 }
 
+#ifndef PT_TLAS_CUBIC
+#define PT_TLAS_CUBIC 1      // cubic cells for the top level as well, now that the large instances are filed apart (C5 +1 %; before that: -2 %)
+#endif
 #ifndef PT_TLAS_LARGE_FIRST
 #define PT_TLAS_LARGE_FIRST 1
 #endif
@@ -97,7 +100,7 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v)      // 21 bits -> ever
 #define PT_TLAS_LARGE_FRACTION 0.25f
 #endif
 __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
-                         const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ index, bool cubic)
+                         const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ index, bool cubic, bool largeFirst)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -106,10 +109,11 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
     float4 lo = boxLo[i], hi = boxHi[i];
     float c[3] = { 0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z) };
     uint32_t q[3];
-    // Triangles: one scale for the three axes (the largest extent). Cells are cubes, so the bits of a short axis start to differ only
-    // where a split along it is as good as one along the others; per-axis scaling cuts a flat mesh into slabs first (C3: 17.0 -> 13.7
-    // node visits per ray, longest walk 158 -> 119, +12 %). Instances keep the per-axis scale: in a top level the short axis is what
-    // separates the few huge boxes (ground, light) from the many small ones (C5: cubic 13.5 visits per ray, per-axis 12.9).
+    // One scale for the three axes (the largest extent): cells are cubes, so the bits of a short axis start to differ only where a
+    // split along it is as good as one along the others; per-axis scaling cuts a flat mesh into slabs first (C3: 17.0 -> 13.7 node
+    // visits per ray, longest walk 158 -> 119, +12 %). (For a top level the per-axis scale was the better one as long as its few huge
+    // boxes -- ground, light -- were filed among the small ones: the short axis separated them. They have their own key bit now.)
+    const float ext0[3] = { ext[0], ext[1], ext[2] };
     if (cubic) {
         const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
         ext[0] = ext[1] = ext[2] = emax;
@@ -121,13 +125,13 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
     }
     uint64_t key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
 #if PT_TLAS_LARGE_FIRST
-    if (!cubic) {
+    if (largeFirst) {
         // Top level: an instance that spans a quarter of the scene along some axis (a ground plane, a sky dome) would blow up the box of
         // every node on its path if it were filed among its small neighbours; the highest key bit files such instances in a subtree of
         // their own, next to the root (the coordinates give up their lowest bit for it). C5: 12.3 -> 11.2 node visits per ray, +6 %; the threshold
         // is not sensitive (1/16 .. 1/2 measured). The same flag on the TRIANGLES of a bottom level loses 5-9 % on C3: there the large ones are many.
         bool large = false;
-        for (int a = 0; a < 3; a++) large = large || (ext[a] > 0.0f && (a == 0 ? hi.x - lo.x : a == 1 ? hi.y - lo.y : hi.z - lo.z) > PT_TLAS_LARGE_FRACTION * ext[a]);
+        for (int a = 0; a < 3; a++) large = large || (ext0[a] > 0.0f && (a == 0 ? hi.x - lo.x : a == 1 ? hi.y - lo.y : hi.z - lo.z) > PT_TLAS_LARGE_FRACTION * ext0[a]);
         key = (key >> 3) | (large ? 1ull << 62 : 0ull);
     }
 #endif
@@ -677,12 +681,12 @@ fail:
 }
 
 // items in b.boxLo/boxHi/bounds -> sorted -> binary tree -> wide nodes in `nodes` (capacity: wide_node_capacity(nleaves)); no sync
-static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem, bool cubicCells, WideNode* nodes, float* rootBounds, hipStream_t stream)
+static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem, bool cubicCells, bool largeFirst, WideNode* nodes, float* rootBounds, hipStream_t stream)
 {
     hipError_t err = hipSuccess;
     const uint32_t nleaves = cdiv(nitems, leafSize);
     if (nitems) {
-        k_morton<<<cdiv(nitems, 256), 256, 0, stream>>>(b.boxLo, b.boxHi, nitems, b.bounds, b.keys, b.index, cubicCells);
+        k_morton<<<cdiv(nitems, 256), 256, 0, stream>>>(b.boxLo, b.boxHi, nitems, b.bounds, b.keys, b.index, cubicCells, largeFirst);
         size_t tmp = b.sortTempBytes;
         BVH_CHECK(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.index, b.indexSorted, nitems, 0, 63, stream));
         k_leaves<<<cdiv(nleaves, 256), 256, 0, stream>>>(b.keysSorted, b.indexSorted, b.boxLo, b.boxHi, nitems, nleaves, leafSize, b.leafKeys, b.leafLo, b.leafHi);
@@ -734,7 +738,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
         }
         BVH_CHECK(hipGetLastError());
     }
-    BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, kMaxLeafTris, kCostTriangle, true, out.nodes, out.rootBounds, stream));
+    BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, kMaxLeafTris, kCostTriangle, true, false, out.nodes, out.rootBounds, stream));
     if (ntris) k_scatter_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, out.tree.indexSorted, out.tree.leafDst, ntris, leafSize, out.tris, out.tree.slotOfPrim);
     BVH_CHECK(hipMemcpyAsync(&hdr, out.tree.header, sizeof hdr, hipMemcpyDeviceToHost, stream));
     BVH_CHECK(hipStreamSynchronize(stream));     // build is a load-time operation (reference: CommandList::End after the BLAS build, Scene.ixx:184-188)
@@ -805,7 +809,7 @@ hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* cons
         k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
         k_instance_boxes<<<cdiv(n, 4), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
-    BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, false, out.nodes, out.rootBounds, stream));
+    BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, PT_TLAS_CUBIC != 0, true, out.nodes, out.rootBounds, stream));
     if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
     BVH_CHECK(hipGetLastError());
 fail:
