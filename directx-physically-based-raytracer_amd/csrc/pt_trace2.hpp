@@ -377,22 +377,32 @@ PT_DEV Hit trace_single(const BlobReader<LDS>& blob, const BlobView& bv, const A
             const uint32_t i = T.x + (uint32_t)__builtin_ctz(T.y);
             T.y &= T.y - 1u;
             if (curInst == ~0u) {                                           // a TLAS "triangle": enter the instance
-                const uint32_t ia = bv.leafInstOff16 + i * kInst16;
-                const f4v mk = blob.ld(ia + 5);
-                const uint32_t ntri = __float_as_uint(mk.y), x = __float_as_uint(mk.w);
-                if ((__float_as_uint(mk.x) & 0xFFu) && ntri != 0u) {
-                    const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2), b0 = blob.ld(ia + 3), b1 = blob.ld(ia + 4);
+                // the entry record (blob section enterOff16): worldToObject | node base, triangle base, count + mask, InstanceIndex | the
+                // BLAS's root node -- one fetch, and the root is visited in the same iteration
+                const uint32_t ia = bv.enterOff16 + i * kInst16;
+                const f4v mk = blob.ld(ia + 3);
+                const uint32_t cm = __float_as_uint(mk.z), ntri = cm & 0x00FFFFFFu, x = __float_as_uint(mk.w);
+                if ((cm >> 24) && ntri != 0u) {
+                    const f4v w0 = blob.ld(ia), w1 = blob.ld(ia + 1), w2 = blob.ld(ia + 2);
+                    const f4v n0 = blob.ld(ia + 4), n1 = blob.ld(ia + 5), n2 = blob.ld(ia + 6), n3 = blob.ld(ia + 7), n4 = blob.ld(ia + 8);
                     ro = V3(sop3t(w0.x, o.x, w0.y, o.y, w0.z, o.z, w0.w), sop3t(w1.x, o.x, w1.y, o.y, w1.z, o.z, w1.w), sop3t(w2.x, o.x, w2.y, o.y, w2.z, o.z, w2.w));
                     const v3 rd = V3(sop3(w0.x, d.x, w0.y, d.y, w0.z, d.z), sop3(w1.x, d.x, w1.y, d.y, w1.z, d.z), sop3(w2.x, d.x, w2.y, d.y, w2.z, d.z));
                     rs = ray_setup(rd);
                     br = box_ray(ro, rd);
-                    nodeBase16 = bv.nodeOff16 + __float_as_uint(b0.w) * kNode16;
-                    triBase16 = bv.triOff16 + __float_as_uint(b1.w) * kTri16;
+                    nodeBase16 = bv.nodeOff16 + __float_as_uint(mk.x) * kNode16;
+                    triBase16 = bv.triOff16 + __float_as_uint(mk.y) * kTri16;
                     PT_LOG(1u, x, T.y);
                     stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
-                    const bool single = blas_single_leaf(ntri);
-                    G = root_node_group(single); T = root_tri_group(single, ntri);
                     curInst = x;
+                    if (blas_single_leaf(ntri)) { G = root_node_group(true); T = root_tri_group(true, ntri); }
+                    else {
+                        if (STATS) stats->nodes++;
+                        PT_LOG(3u, 0u, 0x80000000u);
+                        const uint32_t hits = wide_node_hits(n0, n1, n2, n3, n4, br, tmin, ANYHIT ? tmax : h.t);
+                        G = make_uint2(__float_as_uint(n1.x), (hits & 0xFF000000u) | (__float_as_uint(n0.w) >> 24));
+                        T = make_uint2(__float_as_uint(n1.y), hits & 0x00FFFFFFu);
+                        PT_LOG(4u, G.y, T.y);
+                    }
                 }
             } else {
                 const uint32_t ta = triBase16 + i * kTri16;
