@@ -200,11 +200,20 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
 // ---------------------------------------------------------------------------------------------
 // MODE 0: interleaved TLAS/BLAS walk over the acceleration-structure arrays (any scene). MODE 1 / 2: the flat schedule of
 // pt_trace2.hpp over the scene blob (<= kFlatInstances instances), blob staged in LDS / read from memory.
+#ifndef PT_GBUFFER_SQUARE_WAVES
+#define PT_GBUFFER_SQUARE_WAVES 1
+#endif
 template <bool STATS, bool TEXTURED, int MODE>
 __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, uint32_t flags, PtTextures tx,
                                                  BlobView bv, DeviceCounters* counters)
 {
+#if PT_GBUFFER_SQUARE_WAVES
+    // a wave covers an 8 x 8 pixel square of the block's 16 x 16 tile (not a 16 x 4 strip): its primary rays stay together longer in the tree
+    const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    const uint32_t x = blockIdx.x * 16 + (wv & 1u) * 8u + (ln & 7u), ly = blockIdx.y * 16 + (wv >> 1) * 8u + (ln >> 3);
+#else
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), ly = blockIdx.y * 16 + (threadIdx.x >> 4);
+#endif
     const bool valid = x < fv.width && ly < fv.localRows;
     if (MODE == 0 && !valid) return;                           // no barrier below in this mode: early exit is safe
     const uint32_t y = global_row(fv, valid ? ly : 0u);
