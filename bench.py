@@ -4,8 +4,9 @@
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one frame of the hot path on synthetic inputs already resident in HBM:
-GBufferGeneration::Render + Raytracing::Render (Source/App.cpp:1196-1328) and, for N > 1, the RCCL gather
-of the per-rank row bands to rank 0 + de-interleave. The frame is sharded by 16-row bands (band b -> rank b % N),
+GBufferGeneration::Render + Raytracing::Render (Source/App.cpp:1196-1328) and, for N > 1, the library's RCCL gather
+(pt_gather_bands: grouped ncclSend / ncclRecv of the row bands straight into rank 0's full frame, on the frame's own
+stream). The frame is sharded by 16-row bands (band b -> rank b % N),
 total work is fixed as N grows => "scaling": "strong". Rays = primary (G-buffer) + secondary rays actually
 traced, counted on the device. One JSON line is printed by rank 0.
 
@@ -138,7 +139,7 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="developer aid: a round as two launches (k_shade + k_extend2) instead of the fused k_round, to profile the halves separately")
     ap.add_argument("--rehearse-collective", action="store_true",
-                    help="developer aid for a 1-GPU box: run the N > 1 code path (RCCL process group, gather to rank 0, de-interleave) with world size 1")
+                    help="developer aid for a 1-GPU box: run the N > 1 code path (process group, one RCCL communicator per lane, pt_gather_bands) with world size 1")
     ap.add_argument("--launch-check", action="store_true",
                     help="developer aid / CPU test: stop after the process group is up (gloo, no GPU touched) and print the world size")
     args = ap.parse_args()
@@ -186,15 +187,12 @@ def main():
     import dxpbrt_amd.layouts as L
     import dxpbrt_amd.ptamd as P
     import dxpbrt_amd.scenes as S
-    import dxpbrt_amd.sharding as SH
 
     kind, W, H, spp, bounces, desc = WORKLOADS[args.workload]
     scene, ext = make_scene(kind, W / H, S)
     dynamic = kind == "dynamic"
     if dynamic:
         args.inflight = 1                                       # every frame depends on the structures the previous one updated
-    max_rows = max(P.local_rows(H, r, world, BAND) for r in range(world))
-    offsets = (np.arange(world, dtype=np.uint64) * np.uint64(max_rows * W * 8))
 
     class Lane:
         """One frame in flight: its own HIP stream, library context (path queues, counters) and G-buffer textures. The scene -- vertex
@@ -207,17 +205,19 @@ def main():
                 self.ctx.set_frames_in_flight(max(1, args.inflight))
                 self.scene = P.Scene(self.ctx, scene, device) if owner is None else P.SharedScene(self.ctx, owner.scene)
                 self.renderer = P.Renderer(self.ctx, self.scene, W, H)
-                if collective:                                  # equal-sized gather pieces
-                    self.renderer.textures["Radiance"] = torch.zeros((max_rows, W, 4), dtype=torch.int16, device=device)
-                    for op in (self.renderer.gbuffer, self.renderer.raytracing):
-                        op.Textures = self.renderer.textures
-                self.full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if rank == 0 else None
-                self.gathered = torch.zeros((world, max_rows, W, 4), dtype=torch.int16, device=device) if (rank == 0 and collective) else None
+                self.full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if (rank == 0 and collective) else None
             self.stream.synchronize()
 
     lanes = [Lane()]
     lanes += [Lane(lanes[0]) for _ in range(max(1, args.inflight) - 1)]
     ctx = lanes[0].ctx
+    if collective:
+        # one RCCL communicator per lane (= per stream: frames in flight never share one), made by the library itself; the 128-byte
+        # id of each comes from rank 0 through the process group torch.distributed.run set up
+        for lane in lanes:
+            uid = [P.DeviceContext.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            lane.ctx.comm_init(uid[0], rank, world)
     BASE_FLAGS = 0x10 if args.unfused else 0                   # PT_DEBUG_UNFUSED_ROUNDS
     for lane in lanes:
         lane.ctx.set_debug_flags(BASE_FLAGS)
@@ -241,10 +241,7 @@ def main():
             else:
                 lane.renderer.render(gs)
             if collective:
-                SH.gather_to_root(lane.renderer.textures["Radiance"], rank, world, dist, out=lane.gathered)
-                if rank == 0:
-                    lane.ctx.check(lane.ctx.lib.pt_deinterleave_bands(lane.ctx.handle, lane.full.data_ptr(), lane.gathered.data_ptr(),
-                                                                      offsets.ctypes.data, world, BAND, W, H, 8))
+                lane.ctx.gather_bands(lane.renderer.textures["Radiance"], lane.full, W, H, 8, 0)
         return gs
 
     def barrier():
@@ -295,7 +292,7 @@ def main():
                        "scene_copies_per_gpu": 1, "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
                        "bvh": {"node_bytes": acc.NodeSizeBytes, "nodes_total_bytes": acc.NodeBytes, "triangles_total_bytes": acc.TriangleBytes,
                                "bottom_level_depth": acc.MaxBottomLevelDepth, "top_level_depth": acc.TopLevelDepth, "traversal_copy_bytes": acc.BlobBytes},
-                       "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "sharding": f"{BAND}-row bands, band b -> rank b % {world}" + (", pt_gather_bands (grouped ncclSend / ncclRecv into rank 0's frame)" if collective else ""),
                        "rccl_world_size": dist.get_world_size() if collective else 1,
                        "parity": "bit-identical to oracle on this scene (tests/test_gpu_parity.py, tests/test_gpu_fullscale.py)"},
         }
@@ -391,14 +388,28 @@ def main():
         }
         if traffic_note:
             result["roofline"]["traffic_note"] = traffic_note
-        # the bound that actually binds: VALU issue, one wave64 instruction per 4 cycles per SIMD
+        # VALU issue: wave64 instructions per second against what the chip was MEASURED to issue
+        # (tools/valu_peak.hip -> profiles/r03_valu_peak.json: independent v_fma_f32 streams on every SIMD; a SIMD-32 retires a wave64
+        # instruction in 2 cycles once two or more waves feed it -- round 2 priced against the 4 cycles of a lone wave, i.e. half of this)
         if valu:
-            peak_issue = props.multi_processor_count * 4 * clock_hz / 4.0
+            nominal = props.multi_processor_count * 4 * clock_hz / 2.0
+            peak_issue, peak_at_4, peak_src = nominal, None, "nominal: CUs x 4 SIMD-32 x clock / 2 cycles per wave64 instruction"
+            vp = os.path.join(ROOT, "profiles", "r03_valu_peak.json")
+            if os.path.exists(vp):
+                try:
+                    vj = json.load(open(vp))
+                    peak_issue = vj["fma_indep"]["waves_per_simd_8"] * 1e9
+                    peak_at_4 = vj["fma_indep"]["waves_per_simd_4"] * 1e9
+                    peak_src = "measured, profiles/r03_valu_peak.json: independent v_fma_f32, 8 waves per SIMD, all CUs"
+                except Exception:
+                    pass
             issued = valu["wave_instructions_per_frame"] / (latency_ms * 1e-3)
             result["roofline"]["valu_issue"] = {"wave_instructions_per_frame": valu["wave_instructions_per_frame"], "issued_per_s": issued,
-                                                 "peak_per_s": peak_issue, "frac": issued / peak_issue, "clock_hz": clock_hz,
+                                                 "peak_per_s": peak_issue, "peak_source": peak_src, "nominal_peak_per_s": nominal,
+                                                 "peak_per_s_at_4_waves_per_simd": peak_at_4, "frac": issued / peak_issue, "clock_hz": clock_hz,
                                                  "pipelined_frac": valu["wave_instructions_per_frame"] / (ms_per_step * 1e-3) / peak_issue,
-                                                 "note": "SQ_INSTS_VALU of every kernel of a frame (profiles/, same kernel sources) / frame time"}
+                                                 "note": "SQ_INSTS_VALU of every kernel of a frame (profiles/, same kernel sources) / frame time; the render "
+                                                         "kernels hold 4 waves per SIMD (128 VGPRs)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world and not dynamic:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
 

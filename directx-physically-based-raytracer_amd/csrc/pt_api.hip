@@ -8,9 +8,8 @@
 
 using namespace pt;
 
-struct PtContext { Context c; };
-
 static thread_local std::string g_createError;
+namespace pt { std::string& create_error() { return g_createError; } }
 
 static int fail(Context* c, int status, const std::string& msg)
 {
@@ -48,6 +47,15 @@ int pt_create(int device_ordinal, PtContext** out_ctx)
     return PT_OK;
 }
 
+static void detach_from_owner(Context& c)
+{
+    Context* o = c.sceneOwner;
+    if (!o) return;
+    o->borrowers--;
+    for (size_t i = 0; i < o->viewers.size(); i++) if (o->viewers[i] == &c) { o->viewers.erase(o->viewers.begin() + i); break; }
+    c.sceneOwner = nullptr;
+}
+
 static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
 static void free_tlas(Tlas& t)
 {
@@ -63,13 +71,24 @@ void pt_destroy(PtContext* ctx)
     Context& c = ctx->c;
     hipSetDevice(c.device);
     hipStreamSynchronize(c.stream);
+    pt_comm_destroy(ctx);
+    // an owner that is still viewed (pt_share_scene): its viewers lose the scene -- their next render answers PT_ERROR_NOT_READY -- after
+    // their streams have drained, and never touch this context again
+    for (Context* v : c.viewers) {
+        hipStreamSynchronize(v->stream);
+        v->sceneOwner = nullptr; v->tlas = Tlas(); v->blobDev = nullptr; v->blobCapacity = 0; v->blob = BlobView{}; v->haveTlas = false;
+        v->objects = nullptr; v->objectCount = 0; v->instanceData = nullptr; v->instanceDataCount = 0;
+        if (v->graphExec) { hipGraphExecDestroy(v->graphExec); v->graphExec = nullptr; v->graphKey.clear(); }
+    }
+    c.viewers.clear(); c.borrowers = 0;
     for (auto& kv : c.blas) free_blas(kv.second);
-    if (c.sceneOwner) { c.sceneOwner->borrowers--; c.tlas = Tlas(); c.blobDev = nullptr; }       // views: the owner frees them
+    if (c.sceneOwner) { detach_from_owner(c); c.tlas = Tlas(); c.blobDev = nullptr; }       // views: the owner frees them
     free_tlas(c.tlas);
     if (c.heapDev) hipFree(c.heapDev);
     if (c.srgbLutDev) hipFree(c.srgbLutDev);
     if (c.blobDev) hipFree(c.blobDev);
     if (c.tlasUploadDev) hipFree(c.tlasUploadDev);
+    for (auto& st : c.tlasStage) { if (st.host) hipHostFree(st.host); if (st.event) hipEventDestroy(st.event); }
     if (c.tlasHeaderHost) hipHostFree(c.tlasHeaderHost);
     if (c.tlasHeaderEvent) hipEventDestroy(c.tlasHeaderEvent);
     if (c.validateDev) hipFree(c.validateDev);
@@ -238,6 +257,7 @@ int pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDes
     Context& c = ctx->c;
     auto it = c.blas.find(blas_id);
     API_ARG(&c, it != c.blas.end(), "unknown bottom-level id");
+    API_ARG(&c, c.borrowers == 0, "other contexts view this context's scene (pt_share_scene): destroy or re-point them before updating a bottom level");
     int s = check_geometries(c, geometries, geometry_count);
     if (s != PT_OK) return s;
     API_HIP(&c, hipSetDevice(c.device));
@@ -303,7 +323,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     API_ARG(&c, descs || count == 0, "descs is NULL");
     API_ARG(&c, c.borrowers == 0, "other contexts view this context's scene (pt_share_scene): destroy or re-point them before rebuilding");
     API_HIP(&c, hipSetDevice(c.device));
-    if (c.sceneOwner) { c.sceneOwner->borrowers--; c.sceneOwner = nullptr; c.tlas = Tlas(); c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{}; drop_tlas(c); }
+    if (c.sceneOwner) { detach_from_owner(c); c.tlas = Tlas(); c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{}; drop_tlas(c); }
     int st = poll_tlas_header(c, false);
     if (st != PT_OK) return st;
 
@@ -316,6 +336,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     uint32_t blobNodes = tlasNodeCap, blobTris = 0;
     uint64_t tris = 0, objectEnd = 0;
     const size_t srcBytes = sizeof(InstanceSource) * (size_t)count;
+    // staged in pinned host memory, two buffers taken in turn, each guarded by an event recorded behind the copy that read it: the host
+    // may be a build ahead of the stream (a dynamic frame never synchronises) without rewriting bytes a copy has yet to read
     std::vector<uint8_t>& up = c.tlasUploadHost;
     up.resize(srcBytes);
     for (uint32_t i = 0; i < count; i++) {
@@ -386,7 +408,21 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         API_HIP(&c, hipMalloc(&c.tlasUploadDev, up.size() * 2));           // head room: a few more instances next frame do not reallocate
         c.tlasUploadCap = up.size() * 2;
     }
-    API_HIP(&c, hipMemcpyAsync(c.tlasUploadDev, up.data(), up.size(), hipMemcpyHostToDevice, c.stream));   // pageable source: staged before the call returns
+    {
+        Context::UploadStage& st = c.tlasStage[c.tlasStageNext];
+        c.tlasStageNext ^= 1u;
+        if (st.event) API_HIP(&c, hipEventSynchronize(st.event));          // the copy that last read this buffer has run
+        else API_HIP(&c, hipEventCreateWithFlags(&st.event, hipEventDisableTiming));
+        if (up.size() > st.capacity) {
+            if (st.host) hipHostFree(st.host);
+            st.host = nullptr; st.capacity = 0;
+            API_HIP(&c, hipHostMalloc(&st.host, up.size() * 2));
+            st.capacity = up.size() * 2;
+        }
+        memcpy(st.host, up.data(), up.size());
+        API_HIP(&c, hipMemcpyAsync(c.tlasUploadDev, st.host, up.size(), hipMemcpyHostToDevice, c.stream));
+        API_HIP(&c, hipEventRecord(st.event, c.stream));
+    }
     const InstanceSource* dSrc = (const InstanceSource*)c.tlasUploadDev;
     const BlasEntry* dTable = (const BlasEntry*)((const uint8_t*)c.tlasUploadDev + tableOff);
     const BlobCopy* dJobs = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + jobsOff);
@@ -427,7 +463,7 @@ int pt_share_scene(PtContext* ctx, PtContext* source)
     int st = poll_tlas_header(s, true);
     if (st != PT_OK) return fail(&c, st, s.lastError);
     if (!s.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "the source context has no top-level acceleration structure");
-    if (c.sceneOwner) c.sceneOwner->borrowers--;
+    if (c.sceneOwner) detach_from_owner(c);
     else { free_tlas(c.tlas); if (c.blobDev) hipFree(c.blobDev); }
     c.blobDev = nullptr; c.blobCapacity = 0;
     c.tlas = Tlas();
@@ -436,7 +472,7 @@ int pt_share_scene(PtContext* ctx, PtContext* source)
     c.tlasObjectEnd = s.tlasObjectEnd; c.maxBlasDepth = s.maxBlasDepth;
     c.heapHost = s.heapHost; c.heapDirty = true;                            // the descriptor table is copied (each context uploads its own)
     c.objects = s.objects; c.objectCount = s.objectCount; c.instanceData = s.instanceData; c.instanceDataCount = s.instanceDataCount;
-    c.sceneOwner = &s; s.borrowers++;
+    c.sceneOwner = &s; s.borrowers++; s.viewers.push_back(&c);
     c.tlasBlasIds.clear(); c.tlasHeaderPending = false; c.validated = false;
     c.haveTlas = true;
     return PT_OK;
@@ -558,7 +594,10 @@ static int validate_scene(Context& c)
 
 static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv, FrameView& fv, bool needFrameInputs = true)
 {
-    int s = poll_tlas_header(c, false);
+    // A top level whose build has not reported back yet is never rendered: its depth / error word decides whether the traversal stack can
+    // walk it at all. One wait per BUILD (for the build's own kernels, ~0.3 ms of stream work that the frame needs anyway), none per frame
+    // of a static scene; the rest of the frame is enqueued without waiting.
+    int s = poll_tlas_header(c, true);
     if (s != PT_OK) return s;
     if (!c.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "no top-level acceleration structure: call pt_build_top_level first");
     if (needFrameInputs && (!c.haveCamera || !c.haveSceneData)) return fail(&c, PT_ERROR_NOT_READY, "camera / scene data not set");

@@ -37,6 +37,11 @@ __global__ void k_init_bounds(uint32_t* bounds)           // [0..2] = min, [3..5
     else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
 }
 
+__global__ void k_empty_bounds(float* rootBounds)        // an empty tree: lo = +inf, hi = -inf
+{
+    if (threadIdx.x < 6) rootBounds[threadIdx.x] = threadIdx.x < 3 ? INFINITY : -INFINITY;
+}
+
 __device__ __forceinline__ uint32_t load_index(const void* ib, uint32_t stride, uint32_t i)
 {
     return stride == 2 ? (uint32_t)((const uint16_t*)ib)[i] : ((const uint32_t*)ib)[i];
@@ -386,7 +391,7 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
             d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0; d._pad[0] = d._pad[1] = 0;
             d.cost[0] = fminf(cLeaf, cInternal);
             for (int i = 2; i <= 7; i++) {
-                if (dist[i] < d.cost[i - 2]) d.cost[i - 1] = dist[i];
+                if (dist[i] <= d.cost[i - 2]) d.cost[i - 1] = dist[i];          // ties go to MORE roots: zero-area subtrees (all costs 0) still fill eight slots
                 else { d.cost[i - 1] = d.cost[i - 2]; d.split[i] = 0; }
             }
             dp[cur] = d;
@@ -694,8 +699,7 @@ static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leaf
         k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, b.leafLo, b.leafHi, b.children, b.parentInternal, b.parentLeaf, b.nodeLo, b.nodeHi, b.arrival, rootBounds,
                                                      (DpNode*)b.dp, b.range, nitems, leafSize, maxLeafItems, costItem);
     } else {
-        const float e[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
-        BVH_CHECK(hipMemcpyAsync(rootBounds, e, sizeof e, hipMemcpyHostToDevice, stream));
+        k_empty_bounds<<<1, 64, 0, stream>>>(rootBounds);
     }
     {
         CollapseArgs A;
@@ -743,7 +747,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
     BVH_CHECK(hipMemcpyAsync(&hdr, out.tree.header, sizeof hdr, hipMemcpyDeviceToHost, stream));
     BVH_CHECK(hipStreamSynchronize(stream));     // build is a load-time operation (reference: CommandList::End after the BLAS build, Scene.ixx:184-188)
     out.nodeCount = hdr.nodeCount; out.depth = hdr.depth; out.buildError = hdr.error != 0;
-    if ((size_t)hdr.nodeCount * 2 < capacity) {   // the collapse needed far fewer nodes than the worst case: give the rest back
+    if (hdr.nodeCount < capacity && !hdr.error) {  // the collapse needed fewer nodes than the worst case (it always does): give the rest back
         WideNode* exact = nullptr;
         BVH_CHECK(hipMalloc((void**)&exact, sizeof(WideNode) * hdr.nodeCount));
         BVH_CHECK(hipMemcpy(exact, out.nodes, sizeof(WideNode) * hdr.nodeCount, hipMemcpyDeviceToDevice));

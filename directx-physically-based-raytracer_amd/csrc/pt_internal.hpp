@@ -29,8 +29,10 @@ struct TreeBuffers {
     void release();
 };
 
-// wide nodes a tree of nleaves leaves can need: 8-child nodes absorb 7 binary nodes each, the others hold leaves only
-inline uint32_t wide_node_capacity(uint32_t nleaves) { return nleaves * 3u / 5u + 2u; }
+// wide nodes a tree of nleaves leaves can need. A wide node absorbs at least one binary internal node (nleaves - 1 of them), and no more
+// when the cost tables see no gain in opening a child (zero-area subtrees: degenerate triangles, instances of empty meshes): the worst
+// case is one wide node per binary node. Typical trees use ~0.13 nodes per leaf; a static bottom level gives the rest back after its build.
+inline uint32_t wide_node_capacity(uint32_t nleaves) { return nleaves + 1u; }
 
 struct Blas {
     WideNode* nodes = nullptr;
@@ -107,9 +109,12 @@ struct Context {
     Tlas tlas; bool haveTlas = false;
     Context* sceneOwner = nullptr;                    // pt_share_scene: tlas / blob below are views of that context's, never freed here
     int borrowers = 0;                                // contexts viewing THIS context's scene
+    std::vector<Context*> viewers;                    // ... and who they are (pt_destroy of a viewed owner detaches them)
     uint32_t framesInFlight = 1;                      // pt_set_frames_in_flight: how many contexts render concurrently on this GPU (grid sizing)
     std::vector<uint64_t> tlasBlasIds;                // bottom levels the live TLAS refers to (pt_release_bottom_level checks)
     std::vector<uint8_t> tlasUploadHost; void* tlasUploadDev = nullptr; size_t tlasUploadCap = 0;   // InstanceSource | BlasEntry | BlobCopy
+    struct UploadStage { void* host = nullptr; size_t capacity = 0; hipEvent_t event = nullptr; };  // pinned staging of that upload, two in turn
+    UploadStage tlasStage[2]; uint32_t tlasStageNext = 0;
     WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check
     uint32_t maxBlasDepth = 0, tlasInstanceCap = 0;
     size_t blobCapacity = 0;
@@ -136,10 +141,14 @@ struct Context {
     uint64_t lastIterations = 0;
     uint32_t debugFlags = 0;
 
+    void* comm = nullptr; bool commOwned = false; uint32_t commRank = 0, commWorld = 1;   // ncclComm_t of pt_gather_bands (pt_comm.hip)
+
     bool timing = false;
     std::vector<hipEvent_t> evExtend, evShade, evRound;     // begin/end pairs since timing was enabled
     uint32_t nExtend = 0, nShade = 0, nRound = 0;
 };
+
+std::string& create_error();             // pt_api.hip: the message pt_last_error(NULL) returns (errors of the context-free entry points)
 
 // pt_bvh.hip
 hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool allowUpdate, hipStream_t stream, Blas& out);
@@ -166,3 +175,5 @@ hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, c
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 
 } // namespace pt
+
+struct PtContext { pt::Context c; };      // the opaque handle of include/ptamd.h

@@ -861,9 +861,6 @@ constexpr bool kStreamMerge = PT_STREAM_MERGE != 0;         // a node visit and 
 
 // The traversal half alone, same streaming walk: hits go to the queue's hit records (16 B per ray through HBM, nothing next to
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
-#ifndef PT_STREAM_COOP
-#define PT_STREAM_COOP 0     // 1: k_extend_coop instead of k_extend_stream (an experiment that lost, kept for A/B builds: see its comment)
-#endif
 #ifndef PT_EXTSTREAM_WAVES
 #define PT_EXTSTREAM_WAVES 4
 #endif
@@ -1055,223 +1052,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
     if (lane == 0) for (int i = 0; i < 13; i++) atomicAdd((unsigned int*)&counters->mismatchRay[i], prof[i]);
 #endif
 }
-
-#if PT_STREAM_COOP
-// EXPERIMENT (round 2, not the product path; tools/ab.sh coop "-DPT_STREAM_COOP=1"): the streaming traversal with the tests of a
-// step shared by the four waves of a block. Every lane still owns one ray (refill, harvest, stack and the choice of the next action
-// are as in k_extend_stream), but a node visit or a triangle test is posted as an item (record address, owner) to a block-wide
-// list in LDS; after a barrier thread j takes item j -- node items from the front of the list, triangle items from its back --
-// reads the owner's ray from LDS, fetches the record, tests, and writes the result where the owner finds it after a second barrier.
-// A step of k_extend_stream runs its node section for the ~29 of 64 lanes that want it and its triangle section for ~19, in every
-// wave; here the ~115 node items of the block fill two waves and the triangle items one, and a wave that is draining its last rays
-// lends its lanes to the others. Bit-identical results (it passes the whole GPU suite). Measured on C3: VALU wave-instructions of
-// the kernel 20.6 G -> 14.3 G per 18 frames (-30 %), lanes per executed VALU instruction 0.36 -> 0.53 -- and 27 % SLOWER
-// (2245 -> 1646 Mrays/s with three frames in flight, 1434 -> 1185 alone): two barriers and three LDS round trips on the critical path
-// of every step, at the 4 waves per SIMD that 128 VGPRs allow, cost more than the saved issue slots give back. The step latency of a
-// wave, not only the instruction count, is what the streaming walk is bound by.
-constexpr uint32_t kCoopLds = kStreamLdsStack + 256u * 16u * 3u + 256u * 16u * 2u + 256u * 8u + 32u;
-template <bool STATS, bool WRITE_T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREAM_WAVES, PT_EXTSTREAM_WAVES))) void k_extend_coop(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
-                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues;
-    const uint32_t nT = count[sq];
-    const uint32_t seg = sq * segCap;
-    if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
-    if (!nT) return;                                         // block-uniform: no barrier has been reached yet
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    PT_LDS_AS f4v* rr = (PT_LDS_AS f4v*)(PT_LDS_AS void*)(smem + kStreamLdsStack);   // [3][256] the ray of every owner in its current space: o | tmin, 1/d | t of the hit so far, Sx Sy Sz | octant + axis flags
-    PT_LDS_AS f4v* res = rr + 3 * 256;                                                // [2][256] results by owner
-    PT_LDS_AS u2v* wq = (PT_LDS_AS u2v*)(res + 2 * 256);                              // [256] items: record address (16-byte units) | owner
-    PT_LDS_AS uint32_t* ctl = (PT_LDS_AS uint32_t*)(wq + 256);                        // [0..1] node items, [2..3] triangle items, [4..5] "a wave still works", each by parity
-    if (tid < 8u) ctl[tid] = 0u;
-    __syncthreads();
-    BlobReader<false> blob; blob.p = bv.base;
-    uint2 spill[kStackSize - kStreamStackLds];
-    GroupStack<kStreamStackLds> stack; stack.init((PT_LDS_AS void*)smem, spill);
-    v3 wo = V3(0, 0, 0), wd = V3(0, 0, 1); float wtmax = 0.0f;
-    constexpr uint32_t kMarker = 0xFFFFFFFFu;
-    TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
-    uint32_t qi = ~0u, curInst = ~0u, nodeBase16 = bv.nodeOff16, triBase16 = 0, octinv = 0;
-    float tmin = 0.0f;
-    Hit h; h.t = 0.0f; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
-    uint2 G = make_uint2(0u, 0u), T = make_uint2(0u, 0u);
-    bool exhausted = false;
-    const bool oneInstance = bv.instCount == 1u;
-    uint32_t rayNodes = 0, stepNo = 0, iter = 0;
-    // the owner's ray as the testing thread needs it
-    auto put_ray = [&](const BoxRay& b, float tmn, float tmx, const RaySetup& rs) {
-        rr[tid] = (f4v){ b.o.x, b.o.y, b.o.z, tmn };
-        rr[256 + tid] = (f4v){ b.idir.x, b.idir.y, b.idir.z, tmx };
-        rr[512 + tid] = (f4v){ rs.Sx, rs.Sy, rs.Sz, __uint_as_float(b.octinv4 | (rs.c1 ? 1u << 29 : 0u) | (rs.c2 ? 1u << 30 : 0u)) };   // bits 5..7 of a byte of octinv4 are masked off by its users
-    };
-    RaySetup noSetup; noSetup.c1 = noSetup.c2 = false; noSetup.Sx = noSetup.Sy = noSetup.Sz = 0.0f;
-    while (true) {
-        const unsigned long long busy = wave_ballot(qi != ~0u);
-        {   // the block leaves together: every wave keeps serving items until no wave has a ray or a refill left
-            const uint32_t par = iter & 1u; iter++;
-            if (lane == 0 && !(exhausted && !busy)) ctl[4u + par] = 1u;
-            __syncthreads();
-            const uint32_t any = ctl[4u + par];
-            if (tid == 0) ctl[4u + (par ^ 1u)] = 0u;         // read last before this barrier, set next after the step barriers below
-            if (!any) break;
-        }
-        {
-            const unsigned long long idle = ~busy;
-            const uint32_t nIdle = (uint32_t)__popcll(idle);
-            if (!exhausted && (nIdle >= kStreamRefillMin || !busy)) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&cursor[sq], nIdle);
-                base = (uint32_t)__shfl((int)base, 0);
-                if (base + nIdle >= nT) exhausted = true;
-                if (qi == ~0u) {
-                    const uint32_t e = base + (uint32_t)__popcll(idle & ltMask);
-                    if (e < nT) {
-                        const float4 o = q.r0[seg + e], d = q.r1[seg + e];
-                        wo = V3(o.x, o.y, o.z); wd = V3(d.x, d.y, d.z); wtmax = d.w;
-                        qi = e; tmin = o.w; curInst = ~0u; nodeBase16 = bv.nodeOff16;
-                        const BoxRay br = box_ray(wo, wd);
-                        octinv = br.octinv4;
-                        put_ray(br, tmin, d.w, noSetup);
-                        h.t = d.w; h.u = h.v = 0.0f; h.inst = ~0u; h.geom = h.prim = h.slot = 0;
-                        G = root_node_group(oneInstance); T = root_tri_group(oneInstance, 1u);
-                        stack.sp = 0;
-                        if (STATS) rayNodes = st.nodes;
-                    }
-                }
-            }
-        }
-        bool finished = false;
-        #pragma unroll 1
-        for (uint32_t step = 0; step < kStreamSteps; step++, stepNo++) {
-            const uint32_t par = stepNo & 1u;
-            const bool live = qi != ~0u && !finished;
-            const bool top = curInst == ~0u;
-            // what this lane's ray needs: 0 nothing, 1 a node visit, 2 a triangle test, 4 an instance entry (leaf work first)
-            uint32_t act = 0, addr = 0, item = 0;
-            if (live && T.y != 0u) {
-                item = T.x + (uint32_t)__builtin_ctz(T.y);
-                T.y &= T.y - 1u;
-                if (top) { act = 4u; addr = bv.leafInstOff16 + item * kInst16; }
-                else { act = 2u; addr = triBase16 + item * kTri16; }
-            } else if (live && G.y > 0x00FFFFFFu) {
-                act = 1u;
-                const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
-                G.y &= ~(1u << bit);
-                if (G.y > 0x00FFFFFFu) stack.push(G);
-                const uint32_t slot = (bit - 24u) ^ (octinv & 7u);
-                addr = nodeBase16 + (G.x + (uint32_t)__builtin_popcount(G.y & 0xFFu & ~(0xFFFFFFFFu << slot))) * kNode16;
-            }
-            // ---- post the items of the wave
-            {
-                const unsigned long long mN = wave_ballot(act == 1u), mT = wave_ballot(act == 2u);
-                uint32_t baseN = 0, baseT = 0;
-                if (lane == 0) {
-                    if (mN) baseN = __hip_atomic_fetch_add(&ctl[par], (uint32_t)__popcll(mN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (mT) baseT = __hip_atomic_fetch_add(&ctl[2u + par], (uint32_t)__popcll(mT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                baseN = (uint32_t)__shfl((int)baseN, 0); baseT = (uint32_t)__shfl((int)baseT, 0);
-                if (act == 1u) wq[baseN + (uint32_t)__popcll(mN & ltMask)] = (u2v){ addr, tid };
-                if (act == 2u) wq[255u - (baseT + (uint32_t)__popcll(mT & ltMask))] = (u2v){ addr, tid };
-                if (tid == 0) { ctl[par ^ 1u] = 0u; ctl[2u + (par ^ 1u)] = 0u; }     // the other parity: read last in the previous step, added to next in the following one
-            }
-            __syncthreads();
-            // ---- every thread: the item that falls to it, and its own instance entry
-            {
-                const uint32_t nN = ctl[par], nTr = ctl[2u + par];
-                const uint32_t j = (tid + 64u * ((stepNo + blockIdx.x) & 3u)) & 255u;
-                const uint32_t wk = j < nN ? 1u : ((255u - j) < nTr ? 2u : 0u);
-                f4v W0 = undefined_f4v(), W1 = undefined_f4v(), W2 = undefined_f4v(), W3 = undefined_f4v(), W4 = undefined_f4v();
-                f4v L0 = undefined_f4v(), L1 = undefined_f4v(), L2 = undefined_f4v(), L3 = undefined_f4v(), L4 = undefined_f4v(), L5 = undefined_f4v();
-                u2v it = (u2v){ 0u, 0u };
-                if (wk) it = wq[j];
-                const f4v* wrec = blob.p + it.x;
-                if (wk) { W0 = wrec[0]; W1 = wrec[1]; W2 = wrec[2]; }
-                if (wk == 1u) { W3 = wrec[3]; W4 = wrec[4]; }
-                const f4v* rec = blob.p + addr;
-                if (act == 4u) { L0 = rec[0]; L1 = rec[1]; L2 = rec[2]; L3 = rec[3]; L4 = rec[4]; L5 = rec[5]; }
-                if (wk == 1u) {
-                    const f4v R0 = rr[it.y], R1 = rr[256u + it.y];
-                    BoxRay b; b.o = V3(R0.x, R0.y, R0.z); b.idir = V3(R1.x, R1.y, R1.z); b.octinv4 = __float_as_uint(rr[512u + it.y].w);
-                    const uint32_t hits = wide_node_hits(W0, W1, W2, W3, W4, b, R0.w, R1.w);
-                    res[it.y] = (f4v){ W1.x, __uint_as_float((hits & 0xFF000000u) | (__float_as_uint(W0.w) >> 24)), W1.y, __uint_as_float(hits & 0x00FFFFFFu) };
-                }
-                if (wk == 2u) {
-                    const f4v R0 = rr[it.y], R2 = rr[512u + it.y];
-                    RaySetup rs; rs.Sx = R2.x; rs.Sy = R2.y; rs.Sz = R2.z; rs.c1 = (__float_as_uint(R2.w) >> 29) & 1u; rs.c2 = (__float_as_uint(R2.w) >> 30) & 1u;
-                    float t = 0.0f, u = 0.0f, v = 0.0f;
-                    const bool ok = tri_test(rs, V3(R0.x, R0.y, R0.z), V3(W0.x, W0.y, W0.z), V3(W1.x, W1.y, W1.z), V3(W2.x, W2.y, W2.z), t, u, v);
-                    res[it.y] = (f4v){ t, u, v, ok ? 1.0f : 0.0f };
-                    if (ok) res[256u + it.y] = (f4v){ W0.w, W1.w, W2.w, 0.0f };
-                }
-                if (act == 4u) {                                             // enter the instance (or skip it: hidden / empty)
-                    const uint32_t ntri = __float_as_uint(L5.y);
-                    if ((__float_as_uint(L5.x) & 0xFFu) && ntri != 0u) {
-                        const v3 ro = V3(sop3t(L0.x, wo.x, L0.y, wo.y, L0.z, wo.z, L0.w), sop3t(L1.x, wo.x, L1.y, wo.y, L1.z, wo.z, L1.w), sop3t(L2.x, wo.x, L2.y, wo.y, L2.z, wo.z, L2.w));
-                        const v3 rd = V3(sop3(L0.x, wd.x, L0.y, wd.y, L0.z, wd.z), sop3(L1.x, wd.x, L1.y, wd.y, L1.z, wd.z), sop3(L2.x, wd.x, L2.y, wd.y, L2.z, wd.z));
-                        const RaySetup rs = ray_setup(rd);
-                        const BoxRay br = box_ray(ro, rd);
-                        octinv = br.octinv4;
-                        put_ray(br, tmin, h.t, rs);
-                        nodeBase16 = bv.nodeOff16 + __float_as_uint(L3.w) * kNode16;
-                        triBase16 = bv.triOff16 + __float_as_uint(L4.w) * kTri16;
-                        stack.push(G); stack.push(T); stack.push(make_uint2(kMarker, 0u));
-                        const bool single = blas_single_leaf(ntri);
-                        G = root_node_group(single); T = root_tri_group(single, ntri);
-                        curInst = __float_as_uint(L5.w);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- owners take their results
-            if (act == 1u) {
-                if (STATS) st.nodes++;
-                const f4v r = res[tid];
-                G = make_uint2(__float_as_uint(r.x), __float_as_uint(r.y));
-                T = make_uint2(__float_as_uint(r.z), __float_as_uint(r.w));
-            }
-            if (act == 2u) {
-                if (STATS) st.tris++;
-                const f4v r = res[tid];
-                if (r.w != 0.0f) {
-                    const f4v r2 = res[256u + tid];
-                    const float before = h.t;
-                    commit_candidate(ac, __float_as_uint(r2.z), h, tmin, r.x, r.y, r.z, curInst, __float_as_uint(r2.x), __float_as_uint(r2.y), item);
-                    if (h.t != before) ((PT_LDS_AS float*)(rr + 256u + tid))[3] = h.t;
-                }
-            }
-            // ---- tail: a lane with nothing at hand pops (LDS), or its ray is done
-            if (live && !T.y && G.y <= 0x00FFFFFFu) {
-                if (stack.sp > 0) {
-                    const uint2 e = stack.pop();
-                    if (e.x == kMarker && e.y == 0u) {                    // leave the BLAS: back to the world-space ray
-                        if (stack.overflow) { finished = true; stack.sp = 0; }
-                        else {
-                            T = stack.pop(); G = stack.pop();
-                            const BoxRay br = box_ray(wo, wd);
-                            octinv = br.octinv4;
-                            put_ray(br, tmin, h.t, noSetup);
-                            nodeBase16 = bv.nodeOff16; curInst = ~0u;
-                        }
-                    } else if (e.y > 0x00FFFFFFu) G = e;
-                    else T = e;
-                } else finished = true;
-            }
-        }
-        if (finished) {
-            const bool hit = h.inst != ~0u && h.t < wtmax;
-            if (STATS) atomicMax(&counters->maxNodesPerRay, st.nodes - rayNodes);
-            q.hit[seg + qi] = make_uint4(hit ? h.inst : ~0u, h.slot, __float_as_uint(h.u), __float_as_uint(h.v));
-            if (WRITE_T) q.r1[seg + qi].w = h.t;
-            qi = ~0u;
-        }
-    }
-    if (STATS) { atomicAdd(&counters->nodesVisited, (unsigned long long)st.nodes); atomicAdd(&counters->trianglesTested, (unsigned long long)st.tris); }
-    if (st.overflow + stack.overflow) atomicAdd(&counters->stackOverflows, st.overflow + stack.overflow);
-}
-#endif  // PT_STREAM_COOP
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
@@ -1502,11 +1282,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
                 // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
                 const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? (uint32_t)PT_STREAM_GRID_SHARED : (uint32_t)PT_STREAM_GRID_ALONE));
-#if PT_STREAM_COOP
-                #define PT_XS(S, W) k_extend_coop<S, W><<<sgrid, 256, kCoopLds, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
-#else
                 #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
-#endif
                 if (stats) { if (wt) PT_XS(true, true); else PT_XS(true, false); } else { if (wt) PT_XS(false, true); else PT_XS(false, false); }
                 #undef PT_XS
                 timing_end(c, c.evExtend, c.nExtend); c.nExtend++;

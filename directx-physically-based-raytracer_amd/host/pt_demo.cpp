@@ -2,13 +2,21 @@
 // reference-shaped operators of ptamd.hpp (GBufferGeneration / Raytracing / RaytracingHelpers), times it and
 // optionally dumps the radiance for the parity test (tests/test_host_cpp.py compares it with the oracle).
 //
-//   pt_demo [--width W] [--height H] [--spp S] [--bounces B] [--frames N] [--out file.bin]
+//   pt_demo [--width W] [--height H] [--spp S] [--bounces B] [--frames N] [--out file.bin] [--ranks R]
+//
+// --ranks R: one process per GPU. The parent (which never touches a GPU) starts R children `--rank r --world R --id-file F`; rank 0
+// makes the RCCL unique id and leaves it in F, the others pick it up; every rank renders its 16-row bands (BandSharding) and rank 0
+// assembles the frame with pt_gather_bands (grouped ncclSend / ncclRecv over xGMI) -- the timed loop includes the gather. R may be 1
+// (the N > 1 code path on a one-GPU box); R > the number of visible GPUs is refused (RCCL wants one device per rank).
 //
 // The scene construction mirrors scenes.py:cornell_box(variant="ggx") value for value (same double-precision
 // expressions), so both hosts feed the library identical bytes. Build: make -C ../csrc ../pt_demo (hipcc, host code).
 #include <hip/hip_runtime.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -100,19 +108,79 @@ template <typename T> static T* upload(const std::vector<T>& v)
     return d;
 }
 
+// --ranks R: start one child per rank and wait for them (no GPU call has been made in this process, and none will be)
+static int launch_ranks(int argc, char** argv, uint32_t ranks)
+{
+    const std::string idFile = "/tmp/pt_demo_id_" + std::to_string((long)getpid());
+    std::vector<pid_t> pids;
+    for (uint32_t r = 0; r < ranks; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 2; }
+        if (pid == 0) {
+            std::vector<std::string> args(argv, argv + argc);
+            for (const char* extra : { "--rank", "", "--world", "", "--id-file", "" }) args.push_back(extra);
+            args[args.size() - 5] = std::to_string(r); args[args.size() - 3] = std::to_string(ranks); args[args.size() - 1] = idFile;
+            std::vector<char*> cargs;
+            for (auto& a : args) cargs.push_back(a.data());
+            cargs.push_back(nullptr);
+            execv("/proc/self/exe", cargs.data());
+            perror("execv"); _exit(127);
+        }
+        pids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t p : pids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 2; }
+    unlink(idFile.c_str());
+    return rc;
+}
+
+static std::vector<uint8_t> exchange_unique_id(uint32_t rank, const std::string& idFile)
+{
+    std::vector<uint8_t> id(PT_COMM_ID_BYTES);
+    if (rank == 0) {
+        id = BandSharding::UniqueId();
+        const std::string tmp = idFile + ".tmp";
+        FILE* fp = fopen(tmp.c_str(), "wb");
+        if (!fp || fwrite(id.data(), 1, id.size(), fp) != id.size()) throw std::runtime_error("cannot write " + tmp);
+        fclose(fp);
+        if (rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot publish " + idFile);
+        return id;
+    }
+    for (int tries = 0; tries < 1200; tries++) {                    // rank 0 publishes with an atomic rename: a file that exists is complete
+        if (FILE* fp = fopen(idFile.c_str(), "rb")) {
+            const size_t n = fread(id.data(), 1, id.size(), fp);
+            fclose(fp);
+            if (n == id.size()) return id;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+    throw std::runtime_error("rank 0 never published the RCCL unique id");
+}
+
 int main(int argc, char** argv)
 {
-    uint32_t W = 1920, H = 1080, spp = 4, bounces = 8, frames = 10;
-    std::string out;
+    uint32_t W = 1920, H = 1080, spp = 4, bounces = 8, frames = 10, ranks = 0, rank = 0, world = 1;
+    std::string out, idFile;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--width") W = atoi(argv[i + 1]); else if (k == "--height") H = atoi(argv[i + 1]);
         else if (k == "--spp") spp = atoi(argv[i + 1]); else if (k == "--bounces") bounces = atoi(argv[i + 1]);
         else if (k == "--frames") frames = atoi(argv[i + 1]); else if (k == "--out") out = argv[i + 1];
+        else if (k == "--ranks") ranks = atoi(argv[i + 1]); else if (k == "--rank") rank = atoi(argv[i + 1]);
+        else if (k == "--world") world = atoi(argv[i + 1]); else if (k == "--id-file") idFile = argv[i + 1];
     }
+    const bool sharded = !idFile.empty();
+    if (ranks && !sharded) return launch_ranks(argc, argv, ranks);
     try {
+        int deviceCount = 0;
+        HIP_OK(hipGetDeviceCount(&deviceCount));
+        if ((int)world > deviceCount) { fprintf(stderr, "pt_demo: %u ranks need %u GPUs, %d visible\n", world, world, deviceCount); return 4; }
+        HIP_OK(hipSetDevice((int)rank));
         hipStream_t stream; HIP_OK(hipStreamCreate(&stream));
-        CommandList commandList(0, stream);
+        CommandList commandList((int)rank, stream);
+        BandSharding sharding;
+        if (sharded) sharding.Join(commandList, rank, world, exchange_unique_id(rank, idFile).data());
+        const uint32_t localRows = sharding.LocalRows(H);
 
         // ---- scene (scenes.py:cornell_box, variant "ggx")
         const PtMaterial white = make_material(0.73f, 0.73f, 0.73f), red = make_material(0.65f, 0.05f, 0.05f), green = make_material(0.12f, 0.45f, 0.15f);
@@ -180,13 +248,15 @@ int main(int argc, char** argv)
         sd.EnvironmentLightTransform[0] = sd.EnvironmentLightTransform[5] = sd.EnvironmentLightTransform[10] = 1;
 
         // ---- textures (Source/App.cpp:438-455 formats)
-        const size_t px_ = (size_t)W * H;
+        const size_t px_ = (size_t)W * std::max(localRows, 1u), fullPx = (size_t)W * H;     // a rank's textures hold its own rows
         PtTextures tx{}; float* radianceF32 = nullptr;
         auto alloc = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, bytes)); HIP_OK(hipMemset(p, 0, bytes)); return p; };
         tx.Position = alloc(px_ * 16); tx.FlatNormal = alloc(px_ * 4); tx.GeometricNormal = alloc(px_ * 4); tx.LinearDepth = alloc(px_ * 4);
         tx.NormalizedDepth = alloc(px_ * 4); tx.MotionVector = alloc(px_ * 8); tx.BaseColorMetalness = alloc(px_ * 4); tx.NormalRoughness = alloc(px_ * 8);
         tx.IOR = alloc(px_ * 2); tx.Transmission = alloc(px_); tx.Radiance = alloc(px_ * 8);
         tx.RadianceF32 = radianceF32 = (float*)alloc(px_ * 16);
+        void* fullRadiance = sharded && rank == 0 ? alloc(fullPx * 8) : nullptr;      // the assembled frame (R16G16B16A16_FLOAT), root only
+        float* fullRadianceF32 = sharded && rank == 0 && !out.empty() ? (float*)alloc(fullPx * 16) : nullptr;
 
         // ---- App::RenderScene
         GBufferGeneration gbuffer(commandList);
@@ -203,6 +273,7 @@ int main(int argc, char** argv)
             gs.FrameIndex = frameIndex; gs.Bounces = bounces; gs.SamplesPerPixel = spp; gs.IsRussianRouletteEnabled = true;
             raytracing.SetConstants(gs);
             raytracing.Render(commandList, tlas);
+            if (sharded) sharding.GatherBands(commandList, tx.Radiance, fullRadiance, W, H, 8);
         };
         renderFrame(12345);                                         // warm-up
         commandList.End();
@@ -214,14 +285,25 @@ int main(int argc, char** argv)
         ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ThrowIfFailed(commandList.Context, pt_get_counters(commandList.Context, &counters));
         const double rays = (double)(counters.PrimaryRays + counters.SecondaryRays);
-        printf("{\"host\": \"c++\", \"width\": %u, \"height\": %u, \"spp\": %u, \"bounces\": %u, \"frames\": %u, \"rays\": %.0f, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f}\n",
-               W, H, spp, bounces, frames, rays, ms / frames, rays / ms / 1e3);
-        if (!out.empty()) {                                         // last frame rendered has FrameIndex 0
-            std::vector<float> host(px_ * 4);
-            HIP_OK(hipMemcpy(host.data(), radianceF32, px_ * 16, hipMemcpyDeviceToHost));
+        if (!sharded)
+            printf("{\"host\": \"c++\", \"width\": %u, \"height\": %u, \"spp\": %u, \"bounces\": %u, \"frames\": %u, \"rays\": %.0f, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f}\n",
+                   W, H, spp, bounces, frames, rays, ms / frames, rays / ms / 1e3);
+        else       // rays are this rank's; rank 0's time includes every peer's bands arriving
+            printf("{\"host\": \"c++\", \"rank\": %u, \"world\": %u, \"local_rows\": %u, \"width\": %u, \"height\": %u, \"spp\": %u, \"bounces\": %u, \"frames\": %u, \"rays_this_rank\": %.0f, \"ms_per_frame\": %.4f}\n",
+                   rank, world, localRows, W, H, spp, bounces, frames, rays, ms / frames);
+        if (sharded && fullRadianceF32) {                          // parity dump of a sharded run: the fp32 copy, assembled the same way
+            sharding.GatherBands(commandList, radianceF32, fullRadianceF32, W, H, 16);
+            commandList.End();
+        } else if (sharded && !out.empty() && rank != 0) {
+            sharding.GatherBands(commandList, radianceF32, nullptr, W, H, 16);
+            commandList.End();
+        }
+        if (!out.empty() && rank == 0) {                            // last frame rendered has FrameIndex 0
+            std::vector<float> host(fullPx * 4);
+            HIP_OK(hipMemcpy(host.data(), fullRadianceF32 ? fullRadianceF32 : radianceF32, fullPx * 16, hipMemcpyDeviceToHost));
             FILE* fp = fopen(out.c_str(), "wb");
             if (!fp) { fprintf(stderr, "cannot open %s\n", out.c_str()); return 3; }
-            fwrite(host.data(), 16, px_, fp); fclose(fp);
+            fwrite(host.data(), 16, fullPx, fp); fclose(fp);
         }
     } catch (const std::exception& e) {
         fprintf(stderr, "pt_demo: %s\n", e.what());

@@ -51,6 +51,41 @@ struct CommandList {
     void ShareScene(const CommandList& owner) { ThrowIfFailed(Context, pt_share_scene(Context, owner.Context)); }
 };
 
+// Multi-GPU (no reference counterpart: the reference presents from one device). One process per GPU; every rank renders its 16-row
+// bands (pt_set_sharding) and the root assembles the frame with one grouped RCCL exchange over xGMI (pt_gather_bands).
+struct BandSharding {
+    static constexpr uint32_t BandHeight = 16;
+    uint32_t Rank = 0, World = 1;
+
+    // every rank calls this with the same 128-byte id (UniqueId() of one rank, distributed by the caller); returns when all have joined
+    void Join(CommandList& commandList, uint32_t rank, uint32_t world, const void* uniqueId)
+    {
+        Rank = rank; World = world;
+        const PtSharding s{ rank, world, BandHeight, 0 };
+        ThrowIfFailed(commandList.Context, pt_set_sharding(commandList.Context, &s));
+        if (world > 1 || uniqueId) ThrowIfFailed(commandList.Context, pt_comm_init(commandList.Context, uniqueId, rank, world));
+    }
+    static std::vector<uint8_t> UniqueId()
+    {
+        std::vector<uint8_t> id(PT_COMM_ID_BYTES);
+        int s = pt_comm_get_unique_id(id.data());
+        if (s != PT_OK) throw std::system_error(s, std::generic_category(), pt_last_error(nullptr));
+        return id;
+    }
+    uint32_t LocalRows(uint32_t height) const
+    {
+        const PtSharding s{ Rank, World, BandHeight, 0 };
+        uint32_t rows = 0;
+        if (pt_local_rows(&s, height, &rows) != PT_OK) throw std::invalid_argument("invalid sharding");
+        return rows;
+    }
+    // localTexture: this rank's rows of a texture; fullFrame (root only): H x W pixels. Enqueued on the command list's stream.
+    void GatherBands(CommandList& commandList, const void* localTexture, void* fullFrame, uint32_t width, uint32_t height, uint32_t pixelBytes, uint32_t root = 0)
+    {
+        ThrowIfFailed(commandList.Context, pt_gather_bands(commandList.Context, localTexture, fullFrame, width, height, pixelBytes, root));
+    }
+};
+
 // GPUBuffer* / Texture* slots of the reference become plain device pointers here.
 struct GPUBuffer { const void* DevicePointer = nullptr; uint64_t Capacity = 0; uint32_t Stride = 0; };
 

@@ -23,6 +23,7 @@ EXPORTS = [
     "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
     "pt_build_top_level", "pt_get_accel_stats", "pt_share_scene", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
+    "pt_comm_get_unique_id", "pt_comm_init", "pt_comm_adopt", "pt_comm_destroy", "pt_gather_bands", "pt_gather_plan",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
     "pt_set_debug_flags", "pt_debug_read_mismatch", "pt_debug_download_blob", "pt_debug_trace_ray", "pt_enable_kernel_timing", "pt_get_kernel_timing", "pt_get_round_timing",
 ]
@@ -56,6 +57,11 @@ class Textures(C.Structure):
 
 class Sharding(C.Structure):
     _fields_ = [("RankIndex", C.c_uint32), ("RankCount", C.c_uint32), ("BandHeight", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class BandMessage(C.Structure):
+    _fields_ = [("Peer", C.c_uint32), ("IsSend", C.c_uint32), ("Band", C.c_uint32), ("_pad", C.c_uint32),
+                ("LocalOffset", C.c_uint64), ("FullOffset", C.c_uint64), ("Bytes", C.c_uint64)]
 
 
 class Counters(C.Structure):
@@ -112,6 +118,12 @@ def load_library():
         lib.pt_local_rows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.pt_deinterleave_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.pt_comm_get_unique_id.argtypes = [C.c_void_p]
+        lib.pt_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        lib.pt_comm_adopt.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pt_comm_destroy.argtypes = [C.c_void_p]
+        lib.pt_gather_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.pt_gather_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.pt_gbuffer_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pt_trace_visibility.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.pt_bsdf_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -134,6 +146,19 @@ def local_rows(height, rank=0, world=1, band=16):
     if load_library().pt_local_rows(C.byref(s), height, C.byref(out)) != 0:
         raise PtInvalidArgument("invalid sharding")
     return out.value
+
+
+def gather_plan(height, row_bytes, rank, world, band=16, root=0):
+    """pt_gather_plan: the (peer, is_send, band, local_offset, full_offset, bytes) messages rank `rank` issues in a gather. No GPU."""
+    lib = load_library()
+    s = Sharding(rank, world, band, 0)
+    n = C.c_uint32(0)
+    if lib.pt_gather_plan(C.byref(s), height, row_bytes, root, None, 0, C.byref(n)) != 0:
+        raise PtInvalidArgument("invalid sharding / root")
+    msgs = (BandMessage * max(1, n.value))()
+    if lib.pt_gather_plan(C.byref(s), height, row_bytes, root, msgs, n.value, C.byref(n)) != 0:
+        raise PtInvalidArgument("invalid sharding / root")
+    return [(m.Peer, m.IsSend, m.Band, m.LocalOffset, m.FullOffset, m.Bytes) for m in msgs[:n.value]]
 
 
 class DeviceContext:
@@ -211,6 +236,26 @@ class DeviceContext:
         self.check(self.lib.pt_get_accel_stats(self.handle, C.byref(s)))
         return s
 
+    # multi-GPU gather (pt_comm.hip) ------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId through the library: 128 bytes, made by one rank, handed to the others by the caller."""
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        st = lib.pt_comm_get_unique_id(buf)
+        if st != 0:
+            raise PtError(f"pt_comm_get_unique_id failed ({st}): {lib.pt_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self.check(self.lib.pt_comm_init(self.handle, buf, rank, world))
+
+    def gather_bands(self, local, dst_full, width, height, pixel_bytes, root=0):
+        """local / dst_full: CUDA tensors (dst_full may be None on a non-root rank)."""
+        self.check(self.lib.pt_gather_bands(self.handle, C.c_void_p(local.data_ptr()),
+                                            C.c_void_p(dst_full.data_ptr() if dst_full is not None else None), width, height, pixel_bytes, root))
+
     def set_sharding(self, rank, world, band=16):
         s = Sharding(rank, world, band, 0)
         self.check(self.lib.pt_set_sharding(self.handle, C.byref(s)))
@@ -252,6 +297,7 @@ class Scene:
     """Device-side scene: the part of Scene (Source/Scene.ixx:75-403) and App::UpdateScene
     (Source/App.cpp:1016-1074) that feeds the hot path: vertex/index buffers, descriptor heap,
     ObjectData / InstanceData buffers, BLAS per mesh node, TLAS over instances."""
+    SKIN_STAGING_RING = 4          # pinned staging buffers of the joint matrices, taken in turn (SkinSkeletalMeshes)
 
     def __init__(self, ctx, scene, device=None):
         torch = _torch()
@@ -319,13 +365,25 @@ class Scene:
         hv = next(h for m, h, _ in self.desc.geometry if m is mesh)
         hm = int(self.desc._motion_heap[id(mesh)])
         torch = _torch()
-        if id(mesh) not in self._skin_cache:                     # skeletal vertices once; joint matrices: a pinned staging tensor + a device
-            n = int(np.asarray(skeletal_transforms).size)         # tensor that live as long as the scene (no allocation, no wait per frame)
-            self._skin_cache[id(mesh)] = (to_device(mesh.skeletal_vertices, self.device), torch.zeros(n, dtype=torch.float32).pin_memory(),
-                                          torch.zeros(n, dtype=torch.float32, device=self.device))
-        sk, staging, tr = self._skin_cache[id(mesh)]
+        if id(mesh) not in self._skin_cache:                     # skeletal vertices once; joint matrices: a ring of pinned staging tensors
+            n = int(np.asarray(skeletal_transforms).size)         # + a device tensor that live as long as the scene (no allocation per frame)
+            ring = [[torch.zeros(n, dtype=torch.float32).pin_memory(), None] for _ in range(self.SKIN_STAGING_RING)]
+            self._skin_cache[id(mesh)] = [to_device(mesh.skeletal_vertices, self.device), ring,
+                                          torch.zeros(n, dtype=torch.float32, device=self.device), 0]
+        entry = self._skin_cache[id(mesh)]
+        sk, ring, tr = entry[0], entry[1], entry[2]
+        slot = ring[entry[3] % len(ring)]; entry[3] += 1
+        # The host may run frames ahead of the stream (nothing on the dynamic path synchronises): a pinned buffer is rewritten only after
+        # the H2D copy that last read it has run -- the event recorded behind that copy. With the ring that wait is over before it starts
+        # unless the host is a whole ring ahead. The device tensor needs no ring: copy N+1 is stream-ordered behind skin kernel N.
+        staging = slot[0]
+        if slot[1] is not None:
+            slot[1].synchronize()
         staging.copy_(torch.from_numpy(np.ascontiguousarray(skeletal_transforms, np.float32).reshape(-1)))
         tr.copy_(staging, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
         ctx.check(lib.pt_skin_mesh(ctx.handle, C.c_void_p(sk.data_ptr()), C.c_void_p(tr.data_ptr()),
                                    C.c_void_p(self._heap_dev[hv].data_ptr()), C.c_void_p(self._heap_dev[hm].data_ptr()), len(mesh.vertices)))
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTAMD_ABI_VERSION 2
+#define PTAMD_ABI_VERSION 3
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -35,7 +35,8 @@ typedef enum PtStatus {
     PT_ERROR_HIP = -2,                /* reference: ThrowIfFailed(HRESULT) */
     PT_ERROR_OUT_OF_MEMORY = -3,
     PT_ERROR_NOT_READY = -4,          /* render before an acceleration structure exists */
-    PT_ERROR_NO_DEVICE = -5
+    PT_ERROR_NO_DEVICE = -5,
+    PT_ERROR_RCCL = -6                /* an RCCL call failed (message: ncclGetErrorString), or librccl could not be loaded */
 } PtStatus;
 
 /* ------------------------------------------------------------------------------------------
@@ -282,6 +283,36 @@ int  pt_set_instance_data(PtContext* ctx, const PtInstanceData* device_instances
 typedef struct PtSharding { uint32_t RankIndex, RankCount, BandHeight, _pad; } PtSharding;
 int  pt_set_sharding(PtContext* ctx, const PtSharding* sharding);
 int  pt_local_rows(const PtSharding* sharding, uint32_t frame_height, uint32_t* out_rows);
+/* The gather (north_star: "image tiles shard naturally across the 8 GPUs of one node with a final RCCL gather over xGMI"; the
+ * reference is single-GPU: Source/App.cpp:1157-1329 renders and presents on one device). One communicator per context, i.e. per
+ * stream: frames in flight on separate streams never share one. RCCL (librccl.so.1) is loaded at the first of these calls.
+ *   pt_comm_get_unique_id  ncclGetUniqueId: PT_COMM_ID_BYTES of host memory, made by one rank and handed to the others by the caller
+ *                          (MPI, a file, torch.distributed's store ...)
+ *   pt_comm_init           ncclCommInitRank on the context's device; returns when all `world` ranks have called it
+ *   pt_comm_adopt          use an ncclComm_t the caller already owns (not destroyed by the library)
+ *   pt_comm_destroy        also called by pt_destroy
+ *   pt_gather_bands        enqueued on the stream: every non-root rank sends its bands (local_bands: its rows, contiguous, as
+ *                          pt_set_sharding lays a texture out), the root receives each band straight into its rows of
+ *                          dst_full[H][W] (grouped ncclSend / ncclRecv, one per band, no staging copy) and places its own bands
+ *                          with one strided device copy. width * pixel_bytes must be a multiple of 16. Needs a communicator
+ *                          whose rank / size equal the sharding's; with RankCount 1 no communicator is needed and nothing is sent.
+ * Errors of RCCL come back as PT_ERROR_RCCL with ncclGetErrorString in pt_last_error.
+ * pt_gather_plan is the host arithmetic behind it (no GPU, no RCCL): the messages rank sharding->RankIndex issues, in order. With
+ * out == NULL only the count is returned. Tests check that the plans of all ranks pair up and tile the frame. */
+typedef struct PtBandMessage {
+    uint32_t Peer, IsSend, Band, _pad;    /* the other rank | 1 = ncclSend (non-root), 0 = ncclRecv (root) | global band index */
+    uint64_t LocalOffset;                 /* byte offset in the sender's local texture */
+    uint64_t FullOffset;                  /* byte offset in the root's full frame */
+    uint64_t Bytes;
+} PtBandMessage;
+#define PT_COMM_ID_BYTES 128
+int  pt_comm_get_unique_id(void* out_id_host);
+int  pt_comm_init(PtContext* ctx, const void* id_host, uint32_t rank, uint32_t world);
+int  pt_comm_adopt(PtContext* ctx, void* nccl_comm);
+int  pt_comm_destroy(PtContext* ctx);
+int  pt_gather_bands(PtContext* ctx, const void* local_bands, void* dst_full, uint32_t width, uint32_t height, uint32_t pixel_bytes, uint32_t root);
+int  pt_gather_plan(const PtSharding* sharding, uint32_t height, uint64_t row_bytes, uint32_t root, PtBandMessage* out, uint32_t capacity, uint32_t* out_count);
+
 /* dst_full[H][W] (pixel_bytes each) <- gathered[rank][local rows][W] (what a gather of every rank's
  * local buffer yields, rank r at byte offset rank_offsets[r]). Device pointers; enqueued on the stream. */
 int  pt_deinterleave_bands(PtContext* ctx, void* dst_full, const void* gathered, const uint64_t* rank_offsets_host,
@@ -338,6 +369,7 @@ int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_TRAVERSAL_PHASED 0x8u  /* bounce rays: the TLAS-walking phase-aligned schedule even when the scene is small enough for the flat one */
 #define PT_DEBUG_UNFUSED_ROUNDS  0x10u    /* a round = k_shade + k_extend2 (two launches, hit records through HBM) instead of the fused k_round */
 #define PT_DEBUG_LOCKSTEP        0x20u    /* scenes too large for LDS: the lock-step schedules (one tile of rays per wave) instead of the streaming form */
+#define PT_DEBUG_GATHER_LOCAL_ONLY 0x40u  /* pt_gather_bands places the root's own bands and exchanges nothing: lets ONE GPU play every rank in turn (tests) */
 #define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(ptamd):
     for n in names:
         assert hasattr(lib, n), f"libptamd.so does not export {n}"
     assert sorted(ptamd.EXPORTS) == names                       # the Python binding covers the whole header
-    assert lib.pt_abi_version() == 2
+    assert lib.pt_abi_version() == 3
 
 
 def test_struct_sizes_match_reference_layouts(pkg, ptamd):
@@ -102,3 +102,37 @@ def test_sharding_helpers_match_library(ptamd):
     assert np.array_equal(ge_pkg.deinterleave(pieces, 37, 8), full)
     with pytest.raises(ptamd.PtInvalidArgument):
         ptamd.local_rows(10, 3, 2, 16)
+
+
+def test_gather_plans_pair_up_and_tile_the_frame(ptamd):
+    """pt_gather_plan (the host arithmetic of pt_gather_bands, no GPU): over all ranks, every ncclSend meets an ncclRecv of the
+    same size in the same order per peer, the receives plus the root's own bands cover every row of the frame exactly once, and
+    the local offsets walk each sender's texture contiguously."""
+    ge_pkg = __import__("dxpbrt_amd.sharding", fromlist=["x"])
+    for H, W, px in ((1080, 1920, 8), (2160, 3840, 8), (37, 6, 16), (16, 2, 8), (5, 4, 8)):
+        row = W * px
+        for world in (1, 2, 3, 8):
+            for band in (4, 16):
+                for root in sorted({0, world - 1}):
+                    plans = [ptamd.gather_plan(H, row, r, world, band, root) for r in range(world)]
+                    recvs = plans[root]
+                    assert all(not m[1] for m in recvs)
+                    covered = np.zeros(H, np.int32)
+                    for y0, y1, _ in ge_pkg.rank_bands(H, root, world, band):
+                        covered[y0:y1] += 1                                   # the root's own bands never travel
+                    for r in range(world):
+                        if r == root:
+                            continue
+                        sends = plans[r]
+                        assert all(m[1] == 1 and m[0] == root for m in sends)
+                        mine = [m for m in recvs if m[0] == r]
+                        assert [(m[2], m[5], m[4]) for m in mine] == [(m[2], m[5], m[4]) for m in sends]     # same bands, sizes, destinations, same order
+                        off = 0
+                        for (_, _, b, lo, fo, n), (y0, y1, l0) in zip(sends, ge_pkg.rank_bands(H, r, world, band)):
+                            assert lo == off == l0 * row and fo == y0 * row and n == (y1 - y0) * row and b == y0 // band
+                            off += n
+                            covered[y0:y1] += 1
+                        assert off == ge_pkg.local_rows(H, r, world, band) * row
+                    assert np.all(covered == 1)
+    with pytest.raises(ptamd.PtInvalidArgument):
+        ptamd.gather_plan(16, 64, 0, 2, 16, root=2)

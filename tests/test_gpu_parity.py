@@ -341,6 +341,31 @@ def test_pathological_mesh_coincident_centroids_and_diagonal_slivers(gpu, ptamd,
     assert c2.BvhMismatches == 0 and c2.StackOverflows == 0
 
 
+def test_degenerate_meshes_build_and_render(gpu, ptamd, oracle, pkg):
+    """a mesh of zero-area triangles only (collinear and coincident vertices: every collapse cost is 0, so the cost tables
+    see no gain in opening a node) and an instance of it next to ordinary geometry. D3D12 accepts such a mesh; the builder must too
+    (node capacity covers the worst case, ties go to more roots), and the image must be the oracle's brute-force image."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 64, 40
+    n = 700
+    t = np.linspace(-1.0, 1.0, n)[:, None]
+    line = np.array([0.0, 0.1, 1.5]) + t * np.array([1.0, 0.2, 0.4])                # n points on one line
+    pos = np.concatenate([line, line[:1].repeat(8, 0)], 0)                        # + 8 copies of one point
+    i0 = np.arange(n - 2)
+    idx = np.concatenate([np.stack([i0, i0 + 1, i0 + 2], -1).reshape(-1), n + np.arange(6)])      # collinear triples + two point-triangles
+    degenerate = S.Mesh(S.make_vertices(pos), S.make_indices(idx), False, S.material((0.9, 0.1, 0.1)))
+    base = S.cornell_box(aspect=W / H, glass_sphere=True)
+    nodes = list(base.nodes) + [S.MeshNode([degenerate])]
+    objects = list(base.objects) + [S.RenderObject(len(nodes) - 1, S.trs()), S.RenderObject(len(nodes) - 1, S.trs((0.1, 0.2, 0.0), 30.0, (0.5, 0.5, 0.5)))]
+    scene = S.Scene(nodes, objects, base.camera, base.scene_data, name="degenerate").finalize()
+    gs = S.graphics_settings(W, H, spp=2, bounces=4, frame_index=2)
+    out, cnt = gpu_render(ptamd, gpu, scene, gs, W, H)
+    ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
+    assert cnt.StackOverflows == 0 and cnt.PrimaryRays + cnt.SecondaryRays == ref_rays
+    assert_gbuffer_identical(out, ref_gb)
+    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+
+
 def test_traversal_schedules_agree(gpu, ptamd, pkg):
     """The three schedules of the bounce-ray traversal (flat instance scan with wave-compacted work items, phase-aligned TLAS
     walk, interleaved TLAS/BLAS) share tri_test / is_better, and a round is either one fused launch (k_round) or the
@@ -444,6 +469,37 @@ def test_device_deinterleave(gpu, ptamd):
     gpu.check(gpu.lib.pt_deinterleave_bands(gpu.handle, d_out.data_ptr(), d_g.data_ptr(), offs.ctypes.data, world, band, W, H, 8))
     gpu.sync()
     assert np.array_equal(d_out.cpu().numpy().view(np.uint16), full)
+
+
+def test_gather_bands_one_gpu_plays_every_rank(gpu, ptamd):
+    """pt_gather_bands with PT_DEBUG_GATHER_LOCAL_ONLY: rank r's bands go to their rows of the full frame and nothing is exchanged,
+    so one GPU can play every rank in turn (root = r): after all of them the frame is complete. Without the flag and without a
+    communicator a sharded gather is refused; with one rank it is a plain copy and needs no communicator."""
+    import torch
+    ge.load_package()
+    import dxpbrt_amd.sharding as SH
+    rng = np.random.default_rng(1)
+    for (H, W, world, band, px) in ((45, 24, 4, 8, 8), (1080, 64, 8, 16, 8), (33, 8, 3, 16, 16)):
+        full = rng.integers(0, 2 ** 31, (H, W, px // 4), dtype=np.int64).astype(np.int32)
+        d_out = torch.zeros((H, W, px // 4), dtype=torch.int32, device="cuda")
+        gpu.set_debug_flags(0x40)
+        for r in range(world):
+            local = torch.from_numpy(np.ascontiguousarray(SH.extract_local(full, r, world, band))).cuda()
+            gpu.set_sharding(r, world, band)
+            gpu.gather_bands(local, d_out, W, H, px, root=r)
+        gpu.sync()
+        assert np.array_equal(d_out.cpu().numpy(), full)
+        gpu.set_debug_flags(0)
+        gpu.set_sharding(1, world, band)
+        with pytest.raises(ptamd.PtError) as e:
+            gpu.gather_bands(local, d_out, W, H, px, root=0)
+        assert "communicator" in str(e.value)
+        gpu.set_sharding(0, 1, band)
+        d_one = torch.zeros_like(d_out)
+        gpu.gather_bands(torch.from_numpy(full).cuda(), d_one, W, H, px, root=0)
+        gpu.sync()
+        assert np.array_equal(d_one.cpu().numpy(), full)
+    gpu.set_sharding(0, 1, 16)
 
 
 def test_full_size_properties_c2(gpu, ptamd, pkg):

@@ -33,3 +33,17 @@ def test_cpp_host_matches_oracle(tmp_path, oracle, pkg):
     ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=0, want_f32=True, layouts=L)
     assert np.array_equal(got.view(np.uint32), ref_f32.view(np.uint32))          # C++ host builds byte-identical inputs
     assert info["host"] == "c++" and info["rays"] > 2 * W * H
+
+
+@pytest.mark.gpu
+def test_cpp_host_multi_rank_path_assembles_the_same_frame(tmp_path):
+    """pt_demo --ranks 1: the C++ host's N > 1 code path (child process per rank, RCCL unique id through a file, pt_comm_init,
+    pt_gather_bands into the full frame) on the one GPU a test box has; the assembled frame equals the plain run's."""
+    W, H = 160, 90
+    common = ["--width", str(W), "--height", str(H), "--spp", "2", "--bounces", "4", "--frames", "2"]
+    a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    subprocess.check_call([DEMO] + common + ["--out", a])
+    line = subprocess.check_output([DEMO] + common + ["--out", b, "--ranks", "1"], text=True)
+    info = json.loads(line.strip().splitlines()[-1])
+    assert info["world"] == 1 and info["rank"] == 0 and info["local_rows"] == H
+    assert np.array_equal(np.fromfile(a, np.uint32), np.fromfile(b, np.uint32))

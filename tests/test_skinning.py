@@ -103,3 +103,32 @@ def test_update_keeps_the_opaque_flag_of_alpha_tested_geometry(gpu, ptamd, oracl
     opaque = S.dynamic_scene(aspect=W / H); opaque.finalize()
     ref_opaque, _, _ = oracle.render(opaque, gs, accel_mode=0, layouts=L)
     assert not np.array_equal(ref_opaque["Position"], ref_gb["Position"])
+
+
+@pytest.mark.gpu
+def test_dynamic_frames_enqueued_without_synchronisation(gpu, ptamd, oracle, pkg):
+    """skin + update + render for several frames back to back with NO host synchronisation in between (what
+    bench.py --workload dynamic does). Every frame's skinned vertices (a stream-ordered copy taken right after the skin kernel)
+    must be the oracle's for THAT frame's pose: the pinned staging buffer of the joint matrices is a ring guarded by events, so
+    a host that runs ahead cannot overwrite a pose the H2D copy has yet to read."""
+    import torch
+    S = pkg.scenes
+    W, H = 64, 36
+    scene = S.dynamic_scene(aspect=W / H)
+    bar = scene.nodes[2].meshes[0]
+    gpu.set_sharding(0, 1, 16)
+    g = ptamd.Scene(gpu, scene)
+    hv = next(h for m, h, _ in scene.geometry if m is bar)
+    r = ptamd.Renderer(gpu, g, W, H)
+    gpu.sync()
+    poses = [S.bar_pose(7.0 * k - 40.0, 0.01 * k) for k in range(12)]       # more frames than the ring has slots
+    snapshots = []
+    for k, pose in enumerate(poses):
+        g.SkinSkeletalMeshes(bar, pose)
+        snapshots.append(g._heap_dev[hv].clone())                          # stream-ordered behind the skin kernel
+        g.UpdateAccelerationStructures(2)
+        r.render(S.graphics_settings(W, H, spp=1, bounces=2, frame_index=k))
+    gpu.sync()
+    for k, pose in enumerate(poses):                                         # the oracle skins the same sequence (skinning reads the previous position)
+        oracle_skin(oracle, bar, pose)
+        assert np.array_equal(snapshots[k].cpu().numpy(), bar.vertices.view(np.uint8).reshape(-1)), f"frame {k} was skinned with another frame's pose"
