@@ -99,6 +99,7 @@ void pt_destroy(PtContext* ctx)
     }
     if (c.graphExec) hipGraphExecDestroy(c.graphExec);
     if (c.frameConstants) hipFree(c.frameConstants);
+    if (c.primaryRecords) hipFree(c.primaryRecords);
     if (c.pixelAux) hipFree(c.pixelAux);
     if (c.queueCounts) hipFree(c.queueCounts);
     if (c.roundArgs) hipFree(c.roundArgs);

@@ -132,6 +132,7 @@ struct Context {
     void* blobDev = nullptr; BlobView blob{};        // compact traversal copy of TLAS + instances + every referenced BLAS
 
     PathQueue queue[2]{}; uint32_t queueCapacity = 0;
+    uint4* primaryRecords = nullptr; uint32_t primaryCapacity = 0;   // 48 B per local pixel: the primary surface as bounce 0 reads it (k_pt_init)
     float2* pixelAux = nullptr; uint32_t pixelAuxCapacity = 0;   // denoiser modes: first-bounce hit distance | isDiffuse per pixel
     FrameConstants* frameConstants = nullptr;
     hipGraphExec_t graphExec = nullptr; std::string graphKey; bool disableGraphs = false;

@@ -419,7 +419,13 @@ __global__ void k_set_constants(FrameConstants v, FrameConstants* dst, uint32_t*
 // RNG state (all samples of a pixel draw from one stream, Raytracing.hlsl:108,191).
 
 // enqueue every primary-hit pixel as fresh (Raytracing.hlsl:106-127; a primary miss keeps the G-buffer radiance, :241-252)
-__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, float2* aux, uint32_t segCap, uint32_t* countFresh)
+// It also gathers what bounce 0 of every sample re-reads from the G-buffer (Raytracing.hlsl:118-148: eight textures, 47 bytes) into
+// ONE 48-byte record per pixel, bit for bit: rec0 = Position | rec1 = NormalRoughness, FlatNormal, GeometricNormal | rec2 =
+// BaseColorMetalness, Radiance, IOR + Transmission. Here pixels are read in order (coalesced); the fresh entries of later rounds hold
+// pixels in whatever order their paths ended, and eight scattered loads per lane, each using 1..16 bytes of its cache line, were the
+// most expensive part of a round (profiles/r03_round_prof_*.txt: 30 % of a wave's time in the fresh tiles).
+__global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, float2* aux, uint32_t segCap, uint32_t* countFresh,
+                                                 uint4* __restrict__ primary)
 {
     __shared__ uint32_t lds[8];
     const PtGraphicsSettings& gs = fc->gs;
@@ -436,6 +442,11 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConsta
             q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng_init(x, y, gs.FrameIndex)));
             q.s2[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));            // sample 0, bounce 0
             if (aux) aux[p] = make_float2(INFINITY, 1.0f);                               // hitDistance = inf, isDiffuse = true (:188-189)
+            const uint2 nr = ((const uint2*)tx.NormalRoughness)[p], rad = ((const uint2*)tx.Radiance)[p];
+            primary[3 * (size_t)p] = ((const uint4*)tx.Position)[p];
+            primary[3 * (size_t)p + 1] = make_uint4(nr.x, nr.y, ((const uint32_t*)tx.FlatNormal)[p], ((const uint32_t*)tx.GeometricNormal)[p]);
+            primary[3 * (size_t)p + 2] = make_uint4(((const uint32_t*)tx.BaseColorMetalness)[p], rad.x, rad.y,
+                                                    (uint32_t)((const uint16_t*)tx.IOR)[p] | ((uint32_t)((const uint8_t*)tx.Transmission)[p] << 16));
         }
     }
 }
@@ -532,7 +543,7 @@ template <bool LDS> struct GeometryFromBlob {                // ... out of the s
 
 template <bool TEXTURED, typename GEOMETRY>
 PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const PtSceneData& sd, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
-                         PathRegs& p, uint4 hr, float hitT, v3 rayDir, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
+                         PathRegs& p, uint4 hr, float hitT, v3 rayDir, bool& toTraced, bool& toFresh, v3& newO, v3& newD, RoundProf* prof = nullptr)
 {
     bool goes = false; int lobe = 0;
     if (aux && p.sample == 0 && p.bounce == 1) aux[p.pixel].x = hr.x == ~0u ? INFINITY : hitT;        // hitDistance, :235-239
@@ -541,6 +552,7 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
     } else {                                                 // :293-304
         SurfaceHit h;
         reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+        PT_PROF_MARK(prof, 5);
         const PtMaterial m = surface_material<TEXTURED>(sv, h);
         BSDFSample bs;
         bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
@@ -551,7 +563,7 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
 }
 
 // A fresh path: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
-PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux,
+PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux, const uint4* __restrict__ primary,
                         PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
 {
     const uint32_t pixel = p.pixel;
@@ -559,11 +571,12 @@ PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphi
     float uu, vv;
     const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
     const v3 rayDir = primaryRay.d;
-    const float4 pos = ((const float4*)tx.Position)[pixel];
-    const short4 nr = ((const short4*)tx.NormalRoughness)[pixel];
-    const short2 fe = ((const short2*)tx.FlatNormal)[pixel], ge = ((const short2*)tx.GeometricNormal)[pixel];
-    const uchar4 bcm = ((const uchar4*)tx.BaseColorMetalness)[pixel];
-    const ushort4 rad = ((const ushort4*)tx.Radiance)[pixel];
+    const uint4 r0 = primary[3 * (size_t)pixel], r1 = primary[3 * (size_t)pixel + 1], r2 = primary[3 * (size_t)pixel + 2];
+    const float4 pos = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
+    const short4 nr = make_short4((short)(r1.x & 0xFFFFu), (short)(r1.x >> 16), (short)(r1.y & 0xFFFFu), (short)(r1.y >> 16));
+    const short2 fe = make_short2((short)(r1.z & 0xFFFFu), (short)(r1.z >> 16)), ge = make_short2((short)(r1.w & 0xFFFFu), (short)(r1.w >> 16));
+    const uchar4 bcm = make_uchar4((unsigned char)(r2.x & 0xFFu), (unsigned char)((r2.x >> 8) & 0xFFu), (unsigned char)((r2.x >> 16) & 0xFFu), (unsigned char)(r2.x >> 24));
+    const ushort4 rad = make_ushort4((unsigned short)(r2.y & 0xFFFFu), (unsigned short)(r2.y >> 16), (unsigned short)(r2.z & 0xFFFFu), (unsigned short)(r2.z >> 16));
     SurfaceHit h;
     h.Position = V3(pos.x, pos.y, pos.z); h.PositionOffset = pos.w;                  // HitInfo.hlsli:67-79
     h.FlatNormal = oct_decode(snorm16_to_f32(fe.x), snorm16_to_f32(fe.y));
@@ -572,8 +585,8 @@ PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphi
     h.IsFrontFace = dot(h.GeometricNormal, rayDir) < 0.0f;
     const v3 emission = V3(f16_to_f32(rad.x), f16_to_f32(rad.y), f16_to_f32(rad.z));           // :119,197
     const float metal = unorm8_to_f32(bcm.w);
-    const float ior = f16_to_f32(((const uint16_t*)tx.IOR)[pixel]);
-    const float tr = metal < 1.0f ? unorm8_to_f32(((const uint8_t*)tx.Transmission)[pixel]) : 0.0f;   // :146
+    const float ior = f16_to_f32((uint16_t)(r2.w & 0xFFFFu));
+    const float tr = metal < 1.0f ? unorm8_to_f32((uint8_t)((r2.w >> 16) & 0xFFu)) : 0.0f;       // :146
     BSDFSample bs;
     bs.Initialize(V3(unorm8_to_f32(bcm.x), unorm8_to_f32(bcm.y), unorm8_to_f32(bcm.z)), metal, snorm16_to_f32(nr.w), ior, tr, h.IsFrontFace);
     int lobe = 0;
@@ -584,7 +597,11 @@ PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphi
     } else toFresh = end_sample(gs, tx, aux, p);
 }
 
-// compaction + stores of one tile: survivors to the traced region (state + ray), restarts to the fresh region (state)
+// compaction + stores of one tile: survivors to the traced region (state + ray), restarts to the fresh region (state).
+// Block-wide on purpose. Measured on C2 (round 3): a wave-level reservation (one atomic per wave, no barrier, waves free to drift)
+// runs 20 % SLOWER -- 8.6 against 10.8 Grays/s. A block appends the survivors of 256 neighbouring pixels as one run, so a tile of the
+// next round is made of two or three such runs; with 64-entry runs appended in arrival order the neighbourhoods dissolve four times as
+// fast, and coherent tiles are what keeps the item lists of the traversal balanced and the loads of the shading half on few cache lines.
 PT_DEV void emit_tile(const PathQueue& qout, uint32_t seg, uint32_t segCap, uint32_t* countTraced, uint32_t* countFresh, uint32_t* lds,
                       bool toTraced, bool toFresh, const PathRegs& p, v3 newO, v3 newD)
 {
@@ -611,7 +628,8 @@ PT_DEV void emit_tile(const PathQueue& qout, uint32_t seg, uint32_t segCap, uint
 #endif
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
-                                               PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut)
+                                               PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
+                                               const uint4* __restrict__ primary)
 {
     __shared__ uint32_t lds[16];
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
@@ -638,7 +656,7 @@ __global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(SceneView sv, Frame
         PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
         if (local < nF) {
             p = load_path(qin, seg + (segCap - 1u - local));
-            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
+            shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD);
         }
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
     }
@@ -749,6 +767,7 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
 struct RoundArgs {
     SceneView sv; FrameView fv; PtTextures tx; BlobView bv; PathQueue qin, qout;
     const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap, _pad;
+    const uint4* primary;
 };
 
 template <bool TEXTURED, bool LDS, bool FLAT>
@@ -758,6 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const PathQueue& qin = A->qin; const PathQueue& qout = A->qout;
     const FrameConstants* __restrict__ fc = A->fc; float2* aux = A->aux; const uint32_t segCap = A->segCap;
     const uint32_t* countIn = A->countIn; uint32_t* countOut = A->countOut; DeviceCounters* counters = A->counters;
+    const uint4* __restrict__ primary = A->primary;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t lds[16];
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
@@ -767,6 +787,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t seg = sq * segCap;
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
 
+#ifdef PT_ROUND_PROF
+    RoundProf profData; RoundProf* prof = &profData;
+    for (int k = 0; k < 12; k++) profData.acc[k] = 0;
+    profData.last = __builtin_readcyclecounter();
+#else
+    RoundProf* prof = nullptr;
+#endif
     if (bq * 256u < nT) {                                        // block-uniform
         PT_LDS_AS void* ldsStack = (PT_LDS_AS void*)smem;
         BlobReader<LDS> blob;
@@ -789,10 +816,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             PathRegs p = load_path(qin, i);                       // issued before the traversal: its latency hides behind it (registers are
                                                                   // plentiful here, the kernel's budget is set by the shading half)
             if (!valid) { o.w = 1.0f; d.w = 0.0f; }               // empty interval: hits nothing, but the lane still serves work items
+            PT_PROF_MARK(prof, 0);
             Hit h;
             if constexpr (FLAT) {
                 unsigned char* ldsWave = smem + (uint32_t)kStackLdsFlat * 256u * 8u + (threadIdx.x >> 6) * kFlatWaveLds;
-                h = trace_closest_flat<false, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st);
+                h = trace_closest_flat<false, LDS>(blob, bv, ac, V3(o.x, o.y, o.z), V3(d.x, d.y, d.z), o.w, d.w, ldsStack, ldsWave, &st, prof);
             } else {
                 uint32_t* ldsCand = (uint32_t*)(smem + kStackLds2Bytes);
                 unsigned char* ldsWave = smem + kStackLds2Bytes + (uint32_t)kCandidates * 256u * 4u + (threadIdx.x >> 6) * kPhasedWaveLds;
@@ -802,9 +830,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
             if (valid) {
                 shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
-                                       V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD);
+                                       V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD, prof);
             }
+            PT_PROF_MARK(prof, 6);
             emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+            PT_PROF_MARK(prof, 7);
+#ifdef PT_ROUND_PROF
+            prof->acc[11] += 1u;
+#endif
         }
         if (st.overflow) atomicAdd(&counters->stackOverflows, st.overflow);
     }
@@ -814,10 +847,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
         if (local < nF) {
             p = load_path(qin, seg + (segCap - 1u - local));
-            shade_fresh(fv, cam, gs, tx, aux, p, toTraced, toFresh, newO, newD);
+            shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD);
         }
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
     }
+#ifdef PT_ROUND_PROF
+    // developer build only (tools/round_prof.py): per-wave section clocks (in units of 64 cycles) and item tallies through the mismatch record
+    PT_PROF_MARK(prof, 8);
+    if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 12; k++) atomicAdd((unsigned int*)&counters->mismatchRay[k], k < 9 ? (prof->acc[k] >> 6) : prof->acc[k]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1236,6 +1274,12 @@ static hipError_t ensure_queues(Context& c, uint32_t capacity, uint32_t iteratio
         }
         c.queueCapacity = capacity;
     }
+    if (capacity > c.primaryCapacity) {                             // 48 bytes per local pixel (capacity >= pixels)
+        if (c.primaryRecords) hipFree(c.primaryRecords);
+        c.primaryRecords = nullptr; c.primaryCapacity = 0;
+        if ((e = hipMalloc((void**)&c.primaryRecords, (size_t)capacity * 48)) != hipSuccess) return e;
+        c.primaryCapacity = capacity;
+    }
     if (iterations > c.queueCountsCap) {
         if (c.queueCounts) hipFree(c.queueCounts);
         c.queueCountsCap = iterations;
@@ -1257,7 +1301,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
 {
     const uint32_t cstride = kCountStride;                                     // traced + fresh counters + the streaming form's cursor, per round
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues]);
+    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues], c.primaryRecords);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     {
@@ -1272,8 +1316,8 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
                 uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
                 timing_begin(c, c.evShade, c.nShade);
-                if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
-                else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
+                if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
+                else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
                 timing_end(c, c.evShade, c.nShade); c.nShade++;
                 if (r == rounds) break;
                 timing_begin(c, c.evExtend, c.nExtend);
@@ -1310,8 +1354,8 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
-        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout);
+        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
+        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
@@ -1372,7 +1416,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     std::string key;
     key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
     key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
-    key_add(key, c.frameConstants); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
+    key_add(key, c.frameConstants); key_add(key, c.primaryRecords); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
     key_add(key, c.framesInFlight);
     if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
         if (rounds + 1 > c.roundArgsCap) {
@@ -1388,7 +1432,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
             std::memset(&a, 0, sizeof a);
             a.sv = sv; a.fv = fv; a.tx = tx; a.bv = c.blob; a.qin = c.queue[r & 1]; a.qout = c.queue[(r + 1) & 1];
             a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * kCountStride]; a.countOut = &c.queueCounts[(r + 1) * kCountStride];
-            a.counters = c.counters; a.segCap = segCap;
+            a.counters = c.counters; a.segCap = segCap; a.primary = c.primaryRecords;
         }
         if ((e = hipMemcpyAsync(c.roundArgs, host.data(), sizeof(RoundArgs) * (rounds + 1), hipMemcpyHostToDevice, c.stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(c.stream)) != hipSuccess) return e;    // once per change of the scene / frame geometry, never per frame

@@ -20,6 +20,14 @@
 
 namespace pt {
 
+// Developer build only (-DPT_ROUND_PROF, tools/round_prof.py): wave-clock stamps between the sections of a fused round.
+#ifdef PT_ROUND_PROF
+struct RoundProf { uint64_t last; uint32_t acc[12]; };
+#define PT_PROF_MARK(P, i) do { if (P) { const uint64_t now_ = __builtin_readcyclecounter(); (P)->acc[i] += (uint32_t)(now_ - (P)->last); (P)->last = now_; } } while (0)
+#else
+struct RoundProf;
+#define PT_PROF_MARK(P, i) do { } while (0)
+#endif
 
 struct alignas(16) InstanceT {        // 144 B = 9 x 16
     float worldToObject[12];
@@ -243,7 +251,7 @@ constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 8u + 4u * kF
 
 template <bool STATS, bool LDS>
 PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, const AlphaContext& ac, v3 o, v3 d, float tmin, float tmax,
-                              PT_LDS_AS void* ldsStack, unsigned char* ldsWave, TraceStats* stats)
+                              PT_LDS_AS void* ldsStack, unsigned char* ldsWave, TraceStats* stats, RoundProf* prof = nullptr)
 {
     Hit h; h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.inst = ~0u; h.geom = 0; h.prim = 0; h.slot = 0;
     uint32_t quads = 0, meshes = 0;
@@ -264,6 +272,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
         }
         if (STATS) stats->nodes += (bv.instCount * 2u + 4u) / 5u;           // an instance box is 32 B, a node 80 B: counted by bytes
     }
+    PT_PROF_MARK(prof, 1);
 
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -309,6 +318,10 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
         if (total == 0u) break;                                             // nothing left (a level never exceeds 64 <= kFlatItems)
         rays[2 * lane + 1] = (f4v){ d.x, d.y, d.z, h.t };
         __builtin_amdgcn_wave_barrier();
+        PT_PROF_MARK(prof, 2);
+#ifdef PT_ROUND_PROF
+        if (prof) { prof->acc[9] += total; prof->acc[10] += (total + 63u) / 64u; }
+#endif
 
         // ---- process: lane j takes items j, j + 64, ...
         for (uint32_t j = lane; j < total; j += 64u) {
@@ -318,6 +331,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
                                     : trace_item<STATS, LDS, true>(blob, bv, ac, rays, it & 0xFFu, it >> 8, stack, stats);
         }
         __builtin_amdgcn_wave_barrier();
+        PT_PROF_MARK(prof, 3);
 
         // ---- merge: every ray takes the results of its items of this batch, in the order they were listed
         {
@@ -337,6 +351,7 @@ PT_DEV Hit trace_closest_flat(const BlobReader<LDS>& blob, const BlobView& bv, c
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PT_PROF_MARK(prof, 4);
         km = km2; kq = kq2; firstBatch = false;
     }
     stats->overflow += stack.overflow;

@@ -13,7 +13,7 @@ while [ $# -gt 1 ]; do
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_kernels.hip -o $OUT/pt_kernels_$name.o &&
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_bvh.hip -o $OUT/pt_bvh_$name.o &&
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_api.hip -o $OUT/pt_api_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libptamd_$name.so $OUT/pt_api_$name.o $OUT/pt_bvh_$name.o $OUT/pt_kernels_$name.o $CSRC/pt_skin.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libptamd_$name.so $OUT/pt_api_$name.o $OUT/pt_bvh_$name.o $OUT/pt_kernels_$name.o $CSRC/pt_skin.o $CSRC/pt_comm.o -ldl &&
     echo built $name ) &
   if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi
 done
