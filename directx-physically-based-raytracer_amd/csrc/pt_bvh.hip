@@ -318,8 +318,8 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
 //   C(n, 1) = min(C_leaf(n), C_internal(n)),  C_leaf(n) = A_n * P_n * c_item,  C_internal(n) = A_n * c_node + C_distribute(n, 8)
 //   C(n, i) = min(C_distribute(n, i), C(n, i - 1)),   C_distribute(n, j) = min over 0 < k < j of C(left, k) + C(right, j - k)
 // The decisions are kept (which k, leaf or node) and the collapse kernel follows them top-down.
-struct DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[2]; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
-static_assert(sizeof(DpNode) == 40, "layout");
+struct alignas(16) DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[10]; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
+static_assert(sizeof(DpNode) == 48, "layout");
 constexpr float kCostNode = 1.0f;
 #ifndef PT_COST_TRI
 #define PT_COST_TRI 0.6f
@@ -336,6 +336,25 @@ __device__ __forceinline__ float half_area(float4 lo, float4 hi)
     return a == a && dx >= 0.0f ? a : 0.0f;               // empty boxes (inverted, infinite) never attract the collapse
 }
 
+// Hand-off between the threads of ONE launch (a child's box and cost table, written by the thread that finished the child, read by
+// the thread that finishes the parent, on any CU of any XCD). The XCDs' L2s are not coherent with each other and a CU's L1 is never
+// refreshed, so plain stores + __threadfence() -- an L2 write-back and an L1 invalidate per thread and level, ~3.5 us each and worse
+// under load (MI355X_MICROARCH.md, inter-workgroup visibility) -- made this kernel the slowest of the build: 1.92 ms for 250 k
+// triangles. Instead every handed-off byte is stored and loaded with sc1 (write-through / L1 bypass, 16 bytes per access), the
+// storing lane waits for its stores (vmcnt(0)) before its agent-scope arrival atomic, and the lane whose atomic returns 1 (the second
+// arrival) is the one that loads: the guide's measured "sc1 stores -> wait -> atomic add -> the adder that came last loads sc1" form.
+typedef float refit_f4 __attribute__((ext_vector_type(4)));
+// (s_nop 1: a store of more than 8 bytes reads its data registers after issue; the compiler keeps the required wait state for its own stores
+// but cannot see into inline assembly, and did place a write of the data registers right behind this one.)
+__device__ __forceinline__ void store16_sc1(void* p, refit_f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ refit_f4 load16_sc1(const void* p)
+{
+    refit_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float4 as_float4(refit_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+
 __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi,
                         const int2* __restrict__ children, const int* __restrict__ parentInternal, const int* __restrict__ parentLeaf,
                         float4* nodeLo, float4* nodeHi, uint32_t* arrival, float* rootBounds,
@@ -350,32 +369,44 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
     }
     int cur = parentLeaf[l];
     while (cur >= 0) {
-        __threadfence();                                    // publish what this thread wrote below `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // what this lane stored for the node below `cur` has left the CU
+#ifdef PT_REFIT_FENCE
+        __threadfence();
+#endif
         if (atomicAdd(&arrival[cur], 1u) == 0u) return;      // first arrival: the sibling will finish the node
-        __threadfence();                                    // acquire the sibling subtree's boxes
-        arrival[cur] = 0u;                                  // ready for the next refit
+#ifdef PT_REFIT_FENCE
+        __threadfence();
+#endif
+        arrival[cur] = 0u;                                  // ready for the next refit (a later launch)
         const int2 ch = children[cur];
-        const float4 lo0 = ch.x < 0 ? leafLo[~ch.x] : nodeLo[ch.x], hi0 = ch.x < 0 ? leafHi[~ch.x] : nodeHi[ch.x];
-        const float4 lo1 = ch.y < 0 ? leafLo[~ch.y] : nodeLo[ch.y], hi1 = ch.y < 0 ? leafHi[~ch.y] : nodeHi[ch.y];
+        // leaf boxes come from an earlier launch (plain loads); an internal child's box was stored, sc1, by the thread that arrived first
+        const float4 lo0 = ch.x < 0 ? leafLo[~ch.x] : as_float4(load16_sc1(&nodeLo[ch.x])), hi0 = ch.x < 0 ? leafHi[~ch.x] : as_float4(load16_sc1(&nodeHi[ch.x]));
+        const float4 lo1 = ch.y < 0 ? leafLo[~ch.y] : as_float4(load16_sc1(&nodeLo[ch.y])), hi1 = ch.y < 0 ? leafHi[~ch.y] : as_float4(load16_sc1(&nodeHi[ch.y]));
         const float4 lo = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
         const float4 hi = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
-        nodeLo[cur] = lo; nodeHi[cur] = hi;
+        store16_sc1(&nodeLo[cur], (refit_f4){ lo.x, lo.y, lo.z, 0.0f });
+        store16_sc1(&nodeHi[cur], (refit_f4){ hi.x, hi.y, hi.z, 0.0f });
         if (dp) {
             float c[2][7];
+            #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const int r = side ? ch.y : ch.x;
                 if (r < 0) {
                     const uint32_t first = (uint32_t)(~r) * leafSize, cnt = min(leafSize, nitems - first);
                     const float v = half_area(side ? lo1 : lo0, side ? hi1 : hi0) * (float)cnt * costItem;
+                    #pragma unroll
                     for (int i = 0; i < 7; i++) c[side][i] = v;
                 } else {
-                    for (int i = 0; i < 7; i++) c[side][i] = dp[r].cost[i];
+                    const refit_f4 a = load16_sc1(&dp[r]), b2 = load16_sc1((const char*)&dp[r] + 16);       // cost[0..6]
+                    c[side][0] = a.x; c[side][1] = a.y; c[side][2] = a.z; c[side][3] = a.w; c[side][4] = b2.x; c[side][5] = b2.y; c[side][6] = b2.z;
                 }
             }
             DpNode d;
             float dist[9];
+            #pragma unroll
             for (int j = 2; j <= 8; j++) {
                 float best = INFINITY; int bk = 1;
+                #pragma unroll
                 for (int k = 1; k < j; k++) {
                     if (k > 7 || j - k > 7) continue;
                     const float v = c[0][k - 1] + c[1][j - k - 1];
@@ -388,13 +419,17 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
             const uint32_t first = rg.x * leafSize, last = min((rg.y + 1u) * leafSize, nitems), P = last - first;
             const float cLeaf = P <= maxLeafItems ? A * (float)P * costItem : INFINITY;
             const float cInternal = A * kCostNode + dist[8];
-            d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0; d._pad[0] = d._pad[1] = 0;
+            d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0;
+            #pragma unroll
+            for (int i = 0; i < 10; i++) d._pad[i] = 0;
             d.cost[0] = fminf(cLeaf, cInternal);
+            #pragma unroll
             for (int i = 2; i <= 7; i++) {
                 if (dist[i] <= d.cost[i - 2]) d.cost[i - 1] = dist[i];          // ties go to MORE roots: zero-area subtrees (all costs 0) still fill eight slots
                 else { d.cost[i - 1] = d.cost[i - 2]; d.split[i] = 0; }
             }
-            dp[cur] = d;
+            const refit_f4* dv = (const refit_f4*)&d;
+            store16_sc1(&dp[cur], dv[0]); store16_sc1((char*)&dp[cur] + 16, dv[1]); store16_sc1((char*)&dp[cur] + 32, dv[2]);
         }
         if (cur == 0) {
             rootBounds[0] = lo.x; rootBounds[1] = lo.y; rootBounds[2] = lo.z; rootBounds[3] = hi.x; rootBounds[4] = hi.y; rootBounds[5] = hi.z;
@@ -408,6 +443,8 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
 // ---------------------------------------------------------------------------------------------
 constexpr int kEmptyRef = 0x7FFFFFFF;
 constexpr uint32_t kMaxWideLevels = 60;                  // a deeper tree cannot be traversed with kStackSize entries anyway
+constexpr uint32_t kSingleGroupCollapseLeaves = 16384;   // up to here one workgroup collapses the tree in one launch
+constexpr uint32_t kLevelLaunches = 32;                  // per-level launches of the large-tree collapse: 2 * depth + 4 <= kStackSize bounds a traversable tree at 30 levels
 
 __device__ __forceinline__ void ref_box(int r, const float4* leafLo, const float4* leafHi, const float4* nodeLo, const float4* nodeHi, float4& lo, float4& hi)
 {
@@ -468,9 +505,102 @@ struct CollapseArgs {
     WideHeader* header;
 };
 
-// ONE workgroup walks the wide tree level by level (a node's children are allocated by its thread, the next level is the
-// range allocated meanwhile): no inter-workgroup protocol, a loop bound every wave reaches, and a build of 250 k triangles
-// still takes well under a millisecond of a load-time operation.
+// One wide node: w is its index, binaryRootOf[w] the binary node it grows from. Follows the cost tables down to (at most) eight children,
+// deals them to octant-ordered slots, reserves its internal children (consecutive node indices) and its leaf items from the two counters,
+// quantises, writes the node and queues the children (binaryRootOf of their indices).
+__device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodesCtr, uint32_t* itemsCtr, uint32_t* errorFlag)
+{
+    int refs[8]; float4 lo[8], hi[8]; bool leafChild[8];
+    const int root = A.binaryRootOf[w];
+    int n = 0;
+    {   // the children the cost tables chose for this node: distribute 8 roots over the two subtrees, recursively
+        int sref[10]; int sbud[10]; int sp = 0;
+        const int2 c = A.children[root];
+        const int k8 = A.dp[root].split[8];
+        sref[sp] = c.y; sbud[sp++] = 8 - k8;
+        sref[sp] = c.x; sbud[sp++] = k8;
+        while (sp > 0) {
+            const int m = sref[--sp], budget = sbud[sp];
+            if (m < 0 || budget == 1) {
+                if (n < 8) { refs[n] = m; leafChild[n] = m < 0 || A.dp[m].isLeaf; n++; } else *errorFlag = 1u;
+                continue;
+            }
+            const int k = A.dp[m].split[budget];
+            if (k == 0) { sref[sp] = m; sbud[sp++] = budget - 1; }
+            else { const int2 cm = A.children[m]; sref[sp] = cm.y; sbud[sp++] = budget - k; sref[sp] = cm.x; sbud[sp++] = k; }
+        }
+    }
+    for (int k = 0; k < n; k++) ref_box(refs[k], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[k], hi[k]);
+    // slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2,
+    // greedy instead of the auction: repeatedly the cheapest unassigned (child, slot) pair)
+    float4 nlo, nhi;
+    ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
+    const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
+    int slotOf[8], childAt[8];
+    for (int s = 0; s < 8; s++) { childAt[s] = -1; slotOf[s] = -1; }
+    for (int round = 0; round < n; round++) {
+        int bc = -1, bs = -1; float bcost = INFINITY;
+        for (int c = 0; c < n; c++) {
+            if (slotOf[c] >= 0) continue;
+            float dx = 0.5f * (lo[c].x + hi[c].x) - cx, dy = 0.5f * (lo[c].y + hi[c].y) - cy, dz = 0.5f * (lo[c].z + hi[c].z) - cz;
+            if (!(dx == dx)) dx = 0.0f;
+            if (!(dy == dy)) dy = 0.0f;
+            if (!(dz == dz)) dz = 0.0f;
+            for (int s = 0; s < 8; s++) {
+                if (childAt[s] >= 0) continue;
+                const float cost = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
+                if (cost < bcost || bc < 0) { bcost = cost; bc = c; bs = s; }
+            }
+        }
+        slotOf[bc] = bs; childAt[bs] = bc;
+    }
+    // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at
+    // most kMaxLeafTris items (its leaves are consecutive in Morton order, so its items are one range)
+    uint32_t nInternal = 0, nItems = 0, imask = 0, firstItem[8], cntItem[8];
+    for (int s = 0; s < 8; s++) {
+        const int c = childAt[s];
+        if (c < 0) continue;
+        if (!leafChild[c]) { nInternal++; imask |= 1u << s; continue; }
+        uint32_t l0, l1;
+        if (refs[c] < 0) l0 = l1 = (uint32_t)(~refs[c]); else { const uint2 rg = A.range[refs[c]]; l0 = rg.x; l1 = rg.y; }
+        firstItem[c] = l0 * A.leafSize; cntItem[c] = min((l1 + 1u) * A.leafSize, A.nitems) - firstItem[c];
+        nItems += cntItem[c];
+    }
+    const uint32_t childBase = nInternal ? atomicAdd(nodesCtr, nInternal) : 0u;
+    const uint32_t itemBase = nItems ? atomicAdd(itemsCtr, nItems) : 0u;
+    WideNode node; memset(&node, 0, sizeof node);
+    node.childBase = childBase; node.triBase = itemBase; node.expImask = imask << 24;
+    float4 slo[8], shi[8]; int srefs[8];
+    uint32_t ci = 0, ti = 0; uint8_t meta[8];
+    for (int s = 0; s < 8; s++) {
+        const int c = childAt[s];
+        meta[s] = 0; srefs[s] = kEmptyRef; slo[s] = make_float4(0, 0, 0, 0); shi[s] = slo[s];
+        if (c >= 0) {
+            srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
+            if (!leafChild[c]) {
+                if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else *errorFlag = 1u;
+                ci++;
+                meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+            } else {
+                const uint32_t cnt = cntItem[c];
+                if (cnt > kMaxLeafTris || ti + cnt > 24u) *errorFlag = 1u;
+                for (uint32_t l = firstItem[c] / A.leafSize; l * A.leafSize < firstItem[c] + cnt; l++)
+                    A.leafDst[l] = itemBase + ti + (l * A.leafSize - firstItem[c]);
+                meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
+                ti += cnt;
+            }
+        }
+        A.slotRefs[(size_t)w * 8 + s] = srefs[s];
+    }
+    node.meta[0] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
+    node.meta[1] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
+    quantise_node(node, nlo, nhi, slo, shi, srefs);
+    A.nodes[w] = node;
+}
+
+// Small trees (top levels of a few thousand instances, small meshes): ONE workgroup walks the wide tree level by level (a node's
+// children are allocated by its thread, the next level is the range allocated meanwhile): one launch, no inter-workgroup protocol, a
+// loop bound every wave reaches.
 __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
 {
     __shared__ uint32_t sBegin, sEnd, sNodes, sItems, sError;
@@ -494,94 +624,7 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
     for (; level < kMaxWideLevels; level++) {
         const uint32_t begin = sBegin, end = sEnd;
         if (begin >= end) break;
-        for (uint32_t w = begin + tid; w < end; w += blockDim.x) {
-            int refs[8]; float4 lo[8], hi[8]; bool leafChild[8];
-            const int root = A.binaryRootOf[w];
-            int n = 0;
-            {   // the children the cost tables chose for this node: distribute 8 roots over the two subtrees, recursively
-                int sref[10]; int sbud[10]; int sp = 0;
-                const int2 c = A.children[root];
-                const int k8 = A.dp[root].split[8];
-                sref[sp] = c.y; sbud[sp++] = 8 - k8;
-                sref[sp] = c.x; sbud[sp++] = k8;
-                while (sp > 0) {
-                    const int m = sref[--sp], budget = sbud[sp];
-                    if (m < 0 || budget == 1) {
-                        if (n < 8) { refs[n] = m; leafChild[n] = m < 0 || A.dp[m].isLeaf; n++; } else sError = 1;
-                        continue;
-                    }
-                    const int k = A.dp[m].split[budget];
-                    if (k == 0) { sref[sp] = m; sbud[sp++] = budget - 1; }
-                    else { const int2 cm = A.children[m]; sref[sp] = cm.y; sbud[sp++] = budget - k; sref[sp] = cm.x; sbud[sp++] = k; }
-                }
-            }
-            for (int k = 0; k < n; k++) ref_box(refs[k], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[k], hi[k]);
-            // slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2,
-            // greedy instead of the auction: repeatedly the cheapest unassigned (child, slot) pair)
-            float4 nlo, nhi;
-            ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
-            const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
-            int slotOf[8], childAt[8];
-            for (int s = 0; s < 8; s++) { childAt[s] = -1; slotOf[s] = -1; }
-            for (int round = 0; round < n; round++) {
-                int bc = -1, bs = -1; float bcost = INFINITY;
-                for (int c = 0; c < n; c++) {
-                    if (slotOf[c] >= 0) continue;
-                    float dx = 0.5f * (lo[c].x + hi[c].x) - cx, dy = 0.5f * (lo[c].y + hi[c].y) - cy, dz = 0.5f * (lo[c].z + hi[c].z) - cz;
-                    if (!(dx == dx)) dx = 0.0f;
-                    if (!(dy == dy)) dy = 0.0f;
-                    if (!(dz == dz)) dz = 0.0f;
-                    for (int s = 0; s < 8; s++) {
-                        if (childAt[s] >= 0) continue;
-                        const float cost = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
-                        if (cost < bcost || bc < 0) { bcost = cost; bc = c; bs = s; }
-                    }
-                }
-                slotOf[bc] = bs; childAt[bs] = bc;
-            }
-            // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at
-            // most kMaxLeafTris items (its leaves are consecutive in Morton order, so its items are one range)
-            uint32_t nInternal = 0, nItems = 0, imask = 0, firstItem[8], cntItem[8];
-            for (int s = 0; s < 8; s++) {
-                const int c = childAt[s];
-                if (c < 0) continue;
-                if (!leafChild[c]) { nInternal++; imask |= 1u << s; continue; }
-                uint32_t l0, l1;
-                if (refs[c] < 0) l0 = l1 = (uint32_t)(~refs[c]); else { const uint2 rg = A.range[refs[c]]; l0 = rg.x; l1 = rg.y; }
-                firstItem[c] = l0 * A.leafSize; cntItem[c] = min((l1 + 1u) * A.leafSize, A.nitems) - firstItem[c];
-                nItems += cntItem[c];
-            }
-            const uint32_t childBase = nInternal ? atomicAdd(&sNodes, nInternal) : 0u;
-            const uint32_t itemBase = nItems ? atomicAdd(&sItems, nItems) : 0u;
-            WideNode node; memset(&node, 0, sizeof node);
-            node.childBase = childBase; node.triBase = itemBase; node.expImask = imask << 24;
-            float4 slo[8], shi[8]; int srefs[8];
-            uint32_t ci = 0, ti = 0; uint8_t meta[8];
-            for (int s = 0; s < 8; s++) {
-                const int c = childAt[s];
-                meta[s] = 0; srefs[s] = kEmptyRef; slo[s] = make_float4(0, 0, 0, 0); shi[s] = slo[s];
-                if (c >= 0) {
-                    srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
-                    if (!leafChild[c]) {
-                        if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else sError = 1;
-                        ci++;
-                        meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
-                    } else {
-                        const uint32_t cnt = cntItem[c];
-                        if (cnt > kMaxLeafTris || ti + cnt > 24u) sError = 1;
-                        for (uint32_t l = firstItem[c] / A.leafSize; l * A.leafSize < firstItem[c] + cnt; l++)
-                            A.leafDst[l] = itemBase + ti + (l * A.leafSize - firstItem[c]);
-                        meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
-                        ti += cnt;
-                    }
-                }
-                A.slotRefs[(size_t)w * 8 + s] = srefs[s];
-            }
-            node.meta[0] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
-            node.meta[1] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
-            quantise_node(node, nlo, nhi, slo, shi, srefs);
-            A.nodes[w] = node;
-        }
+        for (uint32_t w = begin + tid; w < end; w += blockDim.x) collapse_node(A, w, &sNodes, &sItems, &sError);
         __syncthreads();
         if (tid == 0) { sBegin = end; sEnd = min(sNodes, A.nodeCapacity); }
         __syncthreads();
@@ -590,6 +633,38 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
         A.header->nodeCount = min(sNodes, A.nodeCapacity); A.header->itemCount = sItems; A.header->depth = level;
         A.header->error = (sError || sBegin < sEnd) ? 1u : 0u;       // capacity exceeded (impossible: <= one wide node per binary node) or too deep
     }
+}
+
+// Large trees: one launch per LEVEL, every workgroup of the chip on it (the single workgroup above took 4.45 ms for the 31.6 k nodes of a
+// 250 k-triangle mesh while 255 CUs idled). The level's node range sits in device memory; the last workgroup to finish a level
+// publishes the next range (what the level allocated), so the launches need nothing from the host. The host enqueues kLevelLaunches
+// of them -- as many levels as the traversal stack could walk anyway -- and a launch that finds an empty range returns at once.
+struct CollapseState { uint32_t begin, end, nodes, items, error, ticket, depth, _pad; };
+
+__global__ void k_collapse_begin(CollapseArgs A, CollapseState* st)
+{
+    st->begin = 0; st->end = 1; st->nodes = 1; st->items = 0; st->error = 0; st->ticket = 0; st->depth = 0;
+    A.binaryRootOf[0] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_collapse_level(CollapseArgs A, CollapseState* st)
+{
+    const uint32_t begin = st->begin, end = st->end;               // stable for the whole launch: only its last workgroup rewrites them
+    if (begin >= end) return;
+    for (uint32_t w = begin + blockIdx.x * blockDim.x + threadIdx.x; w < end; w += gridDim.x * blockDim.x) collapse_node(A, w, &st->nodes, &st->items, &st->error);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&st->ticket, 1u) == gridDim.x - 1u) {     // every workgroup has published its nodes
+        __threadfence();
+        st->ticket = 0;
+        st->begin = end; st->end = min(atomicAdd(&st->nodes, 0u), A.nodeCapacity); st->depth += 1u;
+    }
+}
+
+__global__ void k_collapse_end(CollapseArgs A, CollapseState* st)
+{
+    A.header->nodeCount = min(st->nodes, A.nodeCapacity); A.header->itemCount = st->items; A.header->depth = st->depth;
+    A.header->error = (st->error || st->begin < st->end) ? 1u : 0u;             // too deep: levels left when the launches ran out
 }
 
 // after a refit: new boxes into the existing wide nodes (topology, slots, child and triangle references stay)
@@ -637,7 +712,7 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 void TreeBuffers::release()
 {
     void* ptrs[] = { boxLo, boxHi, bounds, keys, keysSorted, index, indexSorted, sortTemp, leafKeys, leafLo, leafHi, children, parentInternal,
-                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header, dp, range };
+                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header, dp, range, collapseState };
     for (void* p : ptrs) if (p) hipFree(p);
     *this = TreeBuffers();
 }
@@ -676,6 +751,7 @@ static hipError_t ensure_tree_buffers(TreeBuffers& b, uint32_t nitems, uint32_t 
     BVH_CHECK(hipMalloc((void**)&b.leafDst, sizeof(uint32_t) * nl));
     if (withPrimSlots) BVH_CHECK(hipMalloc((void**)&b.slotOfPrim, sizeof(uint32_t) * ni));
     BVH_CHECK(hipMalloc((void**)&b.header, sizeof(WideHeader)));
+    BVH_CHECK(hipMalloc(&b.collapseState, 32));
     BVH_CHECK(hipMalloc(&b.dp, sizeof(DpNode) * nint));
     BVH_CHECK(hipMalloc((void**)&b.range, sizeof(uint2) * nint));
     b.itemCapacity = (uint32_t)ni; b.leafCapacity = (uint32_t)nl;
@@ -707,7 +783,13 @@ static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leaf
         A.children = b.children; A.nodeLo = b.nodeLo; A.nodeHi = b.nodeHi; A.leafLo = b.leafLo; A.leafHi = b.leafHi;
         A.nleaves = nleaves; A.nitems = nitems; A.leafSize = leafSize; A.nodes = nodes; A.nodeCapacity = wide_node_capacity(nleaves);
         A.binaryRootOf = b.binaryRootOf; A.slotRefs = b.slotRefs; A.leafDst = b.leafDst; A.header = b.header;
-        k_collapse<<<1, 1024, 0, stream>>>(A);
+        if (nleaves <= kSingleGroupCollapseLeaves) k_collapse<<<1, 1024, 0, stream>>>(A);
+        else {
+            CollapseState* st = (CollapseState*)b.collapseState;
+            k_collapse_begin<<<1, 1, 0, stream>>>(A, st);
+            for (uint32_t level = 0; level < kLevelLaunches; level++) k_collapse_level<<<2048, 64, 0, stream>>>(A, st);
+            k_collapse_end<<<1, 1, 0, stream>>>(A, st);
+        }
     }
     BVH_CHECK(hipGetLastError());
 fail:

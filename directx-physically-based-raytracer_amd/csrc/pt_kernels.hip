@@ -771,7 +771,10 @@ struct RoundArgs {
 };
 
 template <bool TEXTURED, bool LDS, bool FLAT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(const RoundArgs* __restrict__ A)
+#ifndef PT_ROUND_WAVES
+#define PT_ROUND_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_ROUND_WAVES, PT_ROUND_WAVES))) void k_round(const RoundArgs* __restrict__ A)
 {
     const SceneView& sv = A->sv; const FrameView& fv = A->fv; const PtTextures& tx = A->tx; const BlobView& bv = A->bv;
     const PathQueue& qin = A->qin; const PathQueue& qout = A->qout;
