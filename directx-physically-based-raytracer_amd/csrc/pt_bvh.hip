@@ -279,8 +279,7 @@ __device__ __forceinline__ int delta(const uint64_t* keys, int n, int i, int j)
 }
 
 // internal node i in [0, n-1): children + parent links. child < 0 means leaf ~(leaf index).
-__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children, int* __restrict__ parentInternal, int* __restrict__ parentLeaf,
-                         uint2* __restrict__ range)
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children, int* __restrict__ parentInternal, int* __restrict__ parentLeaf)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -304,7 +303,6 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
     int left = (lo == gamma) ? ~gamma : gamma;
     int right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     children[i] = make_int2(left, right);
-    range[i] = make_uint2((uint32_t)lo, (uint32_t)hi);              // leaves [lo, hi] hang below node i: contiguous in Morton order
     if (left < 0) parentLeaf[~left] = i; else parentInternal[left] = i;
     if (right < 0) parentLeaf[~right] = i; else parentInternal[right] = i;
     if (i == 0) parentInternal[0] = -1;
@@ -358,7 +356,7 @@ __device__ __forceinline__ float4 as_float4(refit_f4 v) { return make_float4(v.x
 __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const float4* __restrict__ leafHi,
                         const int2* __restrict__ children, const int* __restrict__ parentInternal, const int* __restrict__ parentLeaf,
                         float4* nodeLo, float4* nodeHi, uint32_t* arrival, float* rootBounds,
-                        DpNode* dp, const uint2* __restrict__ range, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem)
+                        DpNode* dp, uint32_t nitems, uint32_t leafSize, uint32_t maxLeafItems, float costItem)
 {
     int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaves) return;
@@ -384,7 +382,12 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
         const float4 lo1 = ch.y < 0 ? leafLo[~ch.y] : as_float4(load16_sc1(&nodeLo[ch.y])), hi1 = ch.y < 0 ? leafHi[~ch.y] : as_float4(load16_sc1(&nodeHi[ch.y]));
         const float4 lo = make_float4(fminf(lo0.x, lo1.x), fminf(lo0.y, lo1.y), fminf(lo0.z, lo1.z), 0.0f);
         const float4 hi = make_float4(fmaxf(hi0.x, hi1.x), fmaxf(hi0.y, hi1.y), fmaxf(hi0.z, hi1.z), 0.0f);
-        store16_sc1(&nodeLo[cur], (refit_f4){ lo.x, lo.y, lo.z, 0.0f });
+        // items below a node travel up with its box (the w of the low corner): the tree may have any topology (a subtree's leaves need not
+        // be a range of the sorted order)
+        const uint32_t cnt0 = ch.x < 0 ? min(leafSize, nitems - (uint32_t)(~ch.x) * leafSize) : __float_as_uint(lo0.w);
+        const uint32_t cnt1 = ch.y < 0 ? min(leafSize, nitems - (uint32_t)(~ch.y) * leafSize) : __float_as_uint(lo1.w);
+        const uint32_t P = cnt0 + cnt1;
+        store16_sc1(&nodeLo[cur], (refit_f4){ lo.x, lo.y, lo.z, __uint_as_float(P) });
         store16_sc1(&nodeHi[cur], (refit_f4){ hi.x, hi.y, hi.z, 0.0f });
         if (dp) {
             float c[2][7];
@@ -392,8 +395,7 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
             for (int side = 0; side < 2; side++) {
                 const int r = side ? ch.y : ch.x;
                 if (r < 0) {
-                    const uint32_t first = (uint32_t)(~r) * leafSize, cnt = min(leafSize, nitems - first);
-                    const float v = half_area(side ? lo1 : lo0, side ? hi1 : hi0) * (float)cnt * costItem;
+                    const float v = half_area(side ? lo1 : lo0, side ? hi1 : hi0) * (float)(side ? cnt1 : cnt0) * costItem;
                     #pragma unroll
                     for (int i = 0; i < 7; i++) c[side][i] = v;
                 } else {
@@ -415,8 +417,6 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
                 dist[j] = best; d.split[j] = (uint8_t)bk;
             }
             const float A = half_area(lo, hi);
-            const uint2 rg = range[cur];
-            const uint32_t first = rg.x * leafSize, last = min((rg.y + 1u) * leafSize, nitems), P = last - first;
             const float cLeaf = P <= maxLeafItems ? A * (float)P * costItem : INFINITY;
             const float cInternal = A * kCostNode + dist[8];
             d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0;
@@ -495,7 +495,7 @@ __device__ void quantise_node(WideNode& n, float4 nlo, float4 nhi, const float4*
 }
 
 struct CollapseArgs {
-    const DpNode* dp; const uint2* range;
+    const DpNode* dp;
     const int2* children; const float4* nodeLo; const float4* nodeHi; const float4* leafLo; const float4* leafHi;
     uint32_t nleaves, nitems, leafSize;
     WideNode* nodes; uint32_t nodeCapacity;
@@ -554,17 +554,25 @@ __device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodes
         }
         slotOf[bc] = bs; childAt[bs] = bc;
     }
-    // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at
-    // most kMaxLeafTris items (its leaves are consecutive in Morton order, so its items are one range)
-    uint32_t nInternal = 0, nItems = 0, imask = 0, firstItem[8], cntItem[8];
+    // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at most
+    // kMaxLeafTris items: its (at most three) binary leaves are found by walking it -- they need not be neighbours in the sorted order
+    uint32_t nInternal = 0, nItems = 0, imask = 0, cntItem[8], nLeaf[8]; int leafIds[8][kMaxLeafTris];
     for (int s = 0; s < 8; s++) {
         const int c = childAt[s];
         if (c < 0) continue;
         if (!leafChild[c]) { nInternal++; imask |= 1u << s; continue; }
-        uint32_t l0, l1;
-        if (refs[c] < 0) l0 = l1 = (uint32_t)(~refs[c]); else { const uint2 rg = A.range[refs[c]]; l0 = rg.x; l1 = rg.y; }
-        firstItem[c] = l0 * A.leafSize; cntItem[c] = min((l1 + 1u) * A.leafSize, A.nitems) - firstItem[c];
-        nItems += cntItem[c];
+        int st[2 * kMaxLeafTris]; int sp = 0; uint32_t nl = 0, cnt = 0;
+        st[sp++] = refs[c];
+        while (sp > 0) {
+            const int m = st[--sp];
+            if (m < 0) {
+                if (nl < kMaxLeafTris) leafIds[c][nl] = ~m; else *errorFlag = 1u;
+                nl++; cnt += min(A.leafSize, A.nitems - (uint32_t)(~m) * A.leafSize);
+            } else if (sp + 2 <= (int)(2 * kMaxLeafTris)) { const int2 cm = A.children[m]; st[sp++] = cm.y; st[sp++] = cm.x; }
+            else *errorFlag = 1u;
+        }
+        nLeaf[c] = min(nl, kMaxLeafTris); cntItem[c] = cnt;
+        nItems += cnt;
     }
     const uint32_t childBase = nInternal ? atomicAdd(nodesCtr, nInternal) : 0u;
     const uint32_t itemBase = nItems ? atomicAdd(itemsCtr, nItems) : 0u;
@@ -584,8 +592,12 @@ __device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodes
             } else {
                 const uint32_t cnt = cntItem[c];
                 if (cnt > kMaxLeafTris || ti + cnt > 24u) *errorFlag = 1u;
-                for (uint32_t l = firstItem[c] / A.leafSize; l * A.leafSize < firstItem[c] + cnt; l++)
-                    A.leafDst[l] = itemBase + ti + (l * A.leafSize - firstItem[c]);
+                uint32_t run = 0;
+                for (uint32_t k = 0; k < nLeaf[c]; k++) {
+                    const uint32_t l = (uint32_t)leafIds[c][k];
+                    A.leafDst[l] = itemBase + ti + run;
+                    run += min(A.leafSize, A.nitems - l * A.leafSize);
+                }
                 meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
                 ti += cnt;
             }
@@ -712,7 +724,7 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 void TreeBuffers::release()
 {
     void* ptrs[] = { boxLo, boxHi, bounds, keys, keysSorted, index, indexSorted, sortTemp, leafKeys, leafLo, leafHi, children, parentInternal,
-                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header, dp, range, collapseState };
+                     parentLeaf, nodeLo, nodeHi, arrival, binaryRootOf, slotRefs, leafDst, slotOfPrim, header, dp, collapseState };
     for (void* p : ptrs) if (p) hipFree(p);
     *this = TreeBuffers();
 }
@@ -753,7 +765,6 @@ static hipError_t ensure_tree_buffers(TreeBuffers& b, uint32_t nitems, uint32_t 
     BVH_CHECK(hipMalloc((void**)&b.header, sizeof(WideHeader)));
     BVH_CHECK(hipMalloc(&b.collapseState, 32));
     BVH_CHECK(hipMalloc(&b.dp, sizeof(DpNode) * nint));
-    BVH_CHECK(hipMalloc((void**)&b.range, sizeof(uint2) * nint));
     b.itemCapacity = (uint32_t)ni; b.leafCapacity = (uint32_t)nl;
     return hipSuccess;
 fail:
@@ -771,15 +782,15 @@ static hipError_t build_wide_tree(TreeBuffers& b, uint32_t nitems, uint32_t leaf
         size_t tmp = b.sortTempBytes;
         BVH_CHECK(rocprim::radix_sort_pairs(b.sortTemp, tmp, b.keys, b.keysSorted, b.index, b.indexSorted, nitems, 0, 63, stream));
         k_leaves<<<cdiv(nleaves, 256), 256, 0, stream>>>(b.keysSorted, b.indexSorted, b.boxLo, b.boxHi, nitems, nleaves, leafSize, b.leafKeys, b.leafLo, b.leafHi);
-        if (nleaves > 1) k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(b.leafKeys, (int)nleaves, b.children, b.parentInternal, b.parentLeaf, b.range);
+        if (nleaves > 1) k_karras<<<cdiv(nleaves - 1, 256), 256, 0, stream>>>(b.leafKeys, (int)nleaves, b.children, b.parentInternal, b.parentLeaf);
         k_refit<<<cdiv(nleaves, 256), 256, 0, stream>>>((int)nleaves, b.leafLo, b.leafHi, b.children, b.parentInternal, b.parentLeaf, b.nodeLo, b.nodeHi, b.arrival, rootBounds,
-                                                     (DpNode*)b.dp, b.range, nitems, leafSize, maxLeafItems, costItem);
+                                                     (DpNode*)b.dp, nitems, leafSize, maxLeafItems, costItem);
     } else {
         k_empty_bounds<<<1, 64, 0, stream>>>(rootBounds);
     }
     {
         CollapseArgs A;
-        A.dp = (const DpNode*)b.dp; A.range = b.range;
+        A.dp = (const DpNode*)b.dp;
         A.children = b.children; A.nodeLo = b.nodeLo; A.nodeHi = b.nodeHi; A.leafLo = b.leafLo; A.leafHi = b.leafHi;
         A.nleaves = nleaves; A.nitems = nitems; A.leafSize = leafSize; A.nodes = nodes; A.nodeCapacity = wide_node_capacity(nleaves);
         A.binaryRootOf = b.binaryRootOf; A.slotRefs = b.slotRefs; A.leafDst = b.leafDst; A.header = b.header;
@@ -858,7 +869,7 @@ hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
     k_leaves<<<cdiv(b.leafCount, 256), 256, 0, stream>>>(nullptr, b.tree.indexSorted, b.tree.boxLo, b.tree.boxHi, b.triCount, b.leafCount, leafSize,
                                                          nullptr, b.tree.leafLo, b.tree.leafHi);
     k_refit<<<cdiv(b.leafCount, 256), 256, 0, stream>>>((int)b.leafCount, b.tree.leafLo, b.tree.leafHi, b.tree.children, b.tree.parentInternal,
-                                                        b.tree.parentLeaf, b.tree.nodeLo, b.tree.nodeHi, b.tree.arrival, b.rootBounds, nullptr, nullptr, b.triCount, leafSize, 0, 0.0f);
+                                                        b.tree.parentLeaf, b.tree.nodeLo, b.tree.nodeHi, b.tree.arrival, b.rootBounds, nullptr, b.triCount, leafSize, 0, 0.0f);
     if (b.leafCount > 1)
         k_requantise<<<cdiv(b.nodeCount, 256), 256, 0, stream>>>(b.nodeCount, b.nodes, b.tree.binaryRootOf, b.tree.slotRefs, b.tree.leafLo, b.tree.leafHi,
                                                                  b.tree.nodeLo, b.tree.nodeHi);

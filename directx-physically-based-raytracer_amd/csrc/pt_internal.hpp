@@ -24,7 +24,7 @@ struct TreeBuffers {
     float4* nodeLo = nullptr; float4* nodeHi = nullptr; uint32_t* arrival = nullptr;
     int* binaryRootOf = nullptr; int* slotRefs = nullptr; uint32_t* leafDst = nullptr; uint32_t* slotOfPrim = nullptr;
     WideHeader* header = nullptr; void* collapseState = nullptr;
-    void* dp = nullptr; uint2* range = nullptr;     // collapse cost tables / leaf range per binary node
+    void* dp = nullptr;                             // collapse cost tables per binary node
     uint32_t itemCapacity = 0, leafCapacity = 0;
     void release();
 };
