@@ -95,15 +95,8 @@ __device__ __forceinline__ uint64_t expand21(uint32_t v)      // 21 bits -> ever
     return x;
 }
 
-#ifndef PT_TLAS_CUBIC
-#define PT_TLAS_CUBIC 1      // cubic cells for the top level as well, now that the large instances are filed apart (C5 +1 %; before that: -2 %)
-#endif
-#ifndef PT_TLAS_LARGE_FIRST
-#define PT_TLAS_LARGE_FIRST 1
-#endif
-#ifndef PT_TLAS_LARGE_FRACTION
-#define PT_TLAS_LARGE_FRACTION 0.25f
-#endif
+constexpr bool kTlasCubicCells = true;            // cubic cells for the top level as well, now that the large instances are filed apart (C5 +1 %; before that: -2 %)
+constexpr float kTlasLargeFraction = 0.25f;       // an instance spanning this share of the scene along some axis is filed next to the root
 __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restrict__ boxHi, uint32_t n,
                          const uint32_t* __restrict__ bounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ index, bool cubic, bool largeFirst)
 {
@@ -129,17 +122,15 @@ __global__ void k_morton(const float4* __restrict__ boxLo, const float4* __restr
         q[a] = (uint32_t)fminf(fmaxf(f * 2097152.0f, 0.0f), 2097151.0f);
     }
     uint64_t key = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
-#if PT_TLAS_LARGE_FIRST
     if (largeFirst) {
         // Top level: an instance that spans a quarter of the scene along some axis (a ground plane, a sky dome) would blow up the box of
         // every node on its path if it were filed among its small neighbours; the highest key bit files such instances in a subtree of
         // their own, next to the root (the coordinates give up their lowest bit for it). C5: 12.3 -> 11.2 node visits per ray, +6 %; the threshold
         // is not sensitive (1/16 .. 1/2 measured). The same flag on the TRIANGLES of a bottom level loses 5-9 % on C3: there the large ones are many.
         bool large = false;
-        for (int a = 0; a < 3; a++) large = large || (ext0[a] > 0.0f && (a == 0 ? hi.x - lo.x : a == 1 ? hi.y - lo.y : hi.z - lo.z) > PT_TLAS_LARGE_FRACTION * ext0[a]);
+        for (int a = 0; a < 3; a++) large = large || (ext0[a] > 0.0f && (a == 0 ? hi.x - lo.x : a == 1 ? hi.y - lo.y : hi.z - lo.z) > kTlasLargeFraction * ext0[a]);
         key = (key >> 3) | (large ? 1ull << 62 : 0ull);
     }
-#endif
     keys[i] = key;
     index[i] = i;
 }
@@ -319,13 +310,9 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
 struct alignas(16) DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[10]; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
 static_assert(sizeof(DpNode) == 48, "layout");
 constexpr float kCostNode = 1.0f;
-#ifndef PT_COST_TRI
-#define PT_COST_TRI 0.6f
-#define PT_COST_INST 1.0f
-#endif
-constexpr float kCostTriangle = PT_COST_TRI;         // a triangle test against a node visit. By instruction counts (~97 against ~225) 0.4; measured 0.3 -> 0.6: C3 +3 %, C5 +3 %
+constexpr float kCostTriangle = 0.6f;         // a triangle test against a node visit. By instruction counts (~97 against ~225) 0.4; measured 0.3 -> 0.6: C3 +3 %, C5 +3 %
                                                      // (a triangle is also a step of the walk, and steps are what the streaming traversal pays for), flat from 0.6 to 0.9
-constexpr float kCostInstance = PT_COST_INST;        // entering an instance: look-up, ray transform, BLAS root
+constexpr float kCostInstance = 1.0f;        // entering an instance: look-up, ray transform, BLAS root
 
 __device__ __forceinline__ float half_area(float4 lo, float4 hi)
 {
@@ -368,13 +355,7 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
     int cur = parentLeaf[l];
     while (cur >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // what this lane stored for the node below `cur` has left the CU
-#ifdef PT_REFIT_FENCE
-        __threadfence();
-#endif
         if (atomicAdd(&arrival[cur], 1u) == 0u) return;      // first arrival: the sibling will finish the node
-#ifdef PT_REFIT_FENCE
-        __threadfence();
-#endif
         arrival[cur] = 0u;                                  // ready for the next refit (a later launch)
         const int2 ch = children[cur];
         // leaf boxes come from an earlier launch (plain loads); an internal child's box was stored, sc1, by the thread that arrived first
@@ -906,7 +887,7 @@ hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* cons
         k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
         k_instance_boxes<<<cdiv(n, 4), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
-    BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, PT_TLAS_CUBIC != 0, true, out.nodes, out.rootBounds, stream));
+    BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, kTlasCubicCells, true, out.nodes, out.rootBounds, stream));
     if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
     BVH_CHECK(hipGetLastError());
 fail:

@@ -200,20 +200,13 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
 // ---------------------------------------------------------------------------------------------
 // MODE 0: interleaved TLAS/BLAS walk over the acceleration-structure arrays (any scene). MODE 1 / 2: the flat schedule of
 // pt_trace2.hpp over the scene blob (<= kFlatInstances instances), blob staged in LDS / read from memory.
-#ifndef PT_GBUFFER_SQUARE_WAVES
-#define PT_GBUFFER_SQUARE_WAVES 1
-#endif
 template <bool STATS, bool TEXTURED, int MODE>
 __global__ __launch_bounds__(256) void k_gbuffer(SceneView sv, FrameView fv, PtCamera cam, PtSceneData sd, uint32_t flags, PtTextures tx,
                                                  BlobView bv, DeviceCounters* counters)
 {
-#if PT_GBUFFER_SQUARE_WAVES
     // a wave covers an 8 x 8 pixel square of the block's 16 x 16 tile (not a 16 x 4 strip): its primary rays stay together longer in the tree
     const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
     const uint32_t x = blockIdx.x * 16 + (wv & 1u) * 8u + (ln & 7u), ly = blockIdx.y * 16 + (wv >> 1) * 8u + (ln >> 3);
-#else
-    const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), ly = blockIdx.y * 16 + (threadIdx.x >> 4);
-#endif
     const bool valid = x < fv.width && ly < fv.localRows;
     if (MODE == 0 && !valid) return;                           // no barrier below in this mode: early exit is safe
     const uint32_t y = global_row(fv, valid ? ly : 0u);
@@ -618,16 +611,8 @@ PT_DEV void emit_tile(const PathQueue& qout, uint32_t seg, uint32_t segCap, uint
 // counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
 // k_shade<false> wants 132 VGPRs, one more than four waves per SIMD allow; held to 128 it spills nothing and the fourth wave is worth
 // +1.8 % on C3 and +0.7 % on C5 (the kernel waits on its 268 B per ray, not on issue slots)
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
-#endif
-#if PT_SHADE_WAVES
-#define PT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES, PT_SHADE_WAVES)))
-#else
-#define PT_SHADE_ATTR
-#endif
 template <bool TEXTURED>
-__global__ __launch_bounds__(256) PT_SHADE_ATTR void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
                                                const uint4* __restrict__ primary)
 {
@@ -771,10 +756,7 @@ struct RoundArgs {
 };
 
 template <bool TEXTURED, bool LDS, bool FLAT>
-#ifndef PT_ROUND_WAVES
-#define PT_ROUND_WAVES 4
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_ROUND_WAVES, PT_ROUND_WAVES))) void k_round(const RoundArgs* __restrict__ A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(const RoundArgs* __restrict__ A)
 {
     const SceneView& sv = A->sv; const FrameView& fv = A->fv; const PtTextures& tx = A->tx; const BlobView& bv = A->bv;
     const PathQueue& qin = A->qin; const PathQueue& qout = A->qout;
@@ -872,41 +854,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_ROUND_WA
 //   harvest  finished lanes write their hit record; the shading half (k_shade) runs as its own launch, full lanes
 // Same arithmetic, same tie-break: the image is bit-identical to the other schedules
 // (tests/test_gpu_parity.py::test_streaming_and_lockstep_schedules_agree).
-#ifndef PT_STREAM_STEPS
-#define PT_STREAM_STEPS 6
-#define PT_STREAM_REFILL 12
-#define PT_STREAM_MINLANES 8
-#define PT_STREAM_SHARE 1
-#endif
-#ifndef PT_STREAM_GRID_SHARED
-#define PT_STREAM_GRID_SHARED 512
-#define PT_STREAM_GRID_ALONE 1024
-#endif
-#ifndef PT_STREAM_STACK
-#define PT_STREAM_STACK 12
-#endif
-constexpr int kStreamStackLds = PT_STREAM_STACK;      // stack entries per lane in LDS (24 KB per block); deeper ones go to scratch. 6: -3 %, 8: -1 %, 16: +0.5 %
-constexpr uint32_t kStreamSteps = PT_STREAM_STEPS;      // walk steps between two harvests
-constexpr uint32_t kStreamRefillMin = PT_STREAM_REFILL; // idle lanes worth a refill
-constexpr uint32_t kStreamMinLanes = PT_STREAM_MINLANES;   // a section (node visit / triangle test / instance entry) runs in a step when at least this many lanes ...
-constexpr uint32_t kStreamShareShift = PT_STREAM_SHARE;    // ... and at least (lanes of the busiest section >> this) wait for it; the busiest always runs
+constexpr int kStreamStackLds = 12;                   // stack entries per lane in LDS (24 KB per block); deeper ones go to scratch. 6: -3 %, 8: -1 %, 16: +0.5 %
+constexpr uint32_t kStreamSteps = 6;                  // walk steps between two harvests
+constexpr uint32_t kStreamRefillMin = 12;             // idle lanes worth a refill
+constexpr uint32_t kStreamMinLanes = 8;               // a section (node visit / triangle test / instance entry) runs in a step when at least this many lanes ...
+constexpr uint32_t kStreamShareShift = 1;             // ... and at least (lanes of the busiest section >> this) wait for it; the busiest always runs
+constexpr uint32_t kStreamGridShared = 512, kStreamGridAlone = 1024;    // workgroups of a launch: other frames in flight on this GPU / the frame alone
 constexpr uint32_t kStreamLdsStack = (uint32_t)kStreamStackLds * 256u * 8u;
-#ifndef PT_STREAM_TRIPAIRS
-#define PT_STREAM_TRIPAIRS 1
-#endif
-constexpr bool kStreamTriPairs = PT_STREAM_TRIPAIRS != 0;   // two triangles of a leaf group per step
-#ifndef PT_STREAM_MERGE
-#define PT_STREAM_MERGE 0
-#endif
-constexpr bool kStreamMerge = PT_STREAM_MERGE != 0;         // a node visit and a triangle test in one step (measured: no gain over pairs alone, C3 2272 vs 2286, C5 1953 vs 1950: off)
+constexpr bool kStreamTriPairs = true;                // two triangles of a leaf group per step
 
 // The traversal half alone, same streaming walk: hits go to the queue's hit records (16 B per ray through HBM, nothing next to
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
-#ifndef PT_EXTSTREAM_WAVES
-#define PT_EXTSTREAM_WAVES 4
-#endif
 template <bool STATS, bool WRITE_T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREAM_WAVES, PT_EXTSTREAM_WAVES))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
                                                const uint32_t* count, uint32_t* cursor, DeviceCounters* counters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -992,8 +952,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
 #endif
             // What this lane does in the step. The walk is bound by the latency of its steps (decide -> fetch -> test -> pop is one
             // dependent chain), not by the instructions in them, so a triangle step takes two triangles of the leaf group at once (the second
-            // one's record goes where a node's last units would): C3 +4.6 %, C5 +2.6 %. kStreamMerge additionally lets a node visit and a
-            // triangle test share a step (triangle first: a hit shortens the ray before the node's boxes are tested).
+            // one's record goes where a node's last units would): C3 +4.6 %, C5 +2.6 %.
             bool aN = false, aT = false, aT2 = false, aE = false;
             uint32_t addrN = 0, addrT = 0, addrT2 = 0, item = 0, item2 = 0;
             if (leaf && top) {
@@ -1001,7 +960,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PT_EXTSTREA
             } else if (leaf && doTri) {
                 aT = true; item = T.x + (uint32_t)__builtin_ctz(T.y); T.y &= T.y - 1u; addrT = triBase16 + item * kTri16;
             }
-            if (!aE && wantNode && doNode && (kStreamMerge || !aT)) {
+            if (!aE && wantNode && doNode && !aT) {
                 if (T.y) { stack.push(T); T.y = 0u; }                     // postpone (the rest of) the leaf group: the visit brings a new one
                 aN = true;
                 const uint32_t bit = 31u - (uint32_t)__builtin_clz(G.y);
@@ -1328,7 +1287,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
                 // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
                 // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-                const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? (uint32_t)PT_STREAM_GRID_SHARED : (uint32_t)PT_STREAM_GRID_ALONE));
+                const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? kStreamGridShared : kStreamGridAlone));
                 #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, qout, segCap, cout, cout + 2u * kSubQueues, c.counters)
                 if (stats) { if (wt) PT_XS(true, true); else PT_XS(true, false); } else { if (wt) PT_XS(false, true); else PT_XS(false, false); }
                 #undef PT_XS

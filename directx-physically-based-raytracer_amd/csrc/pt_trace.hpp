@@ -71,21 +71,7 @@ struct TraceStats { uint32_t nodes, tris, overflow; };
 constexpr int kStackSize = 64;
 constexpr uint32_t kMaxLeafTris = 3;                      // the unary count of a leaf slot has 3 bits
 // Triangles per BLAS leaf, a function of the BLAS size so that builder and traversal agree without storing it.
-#ifndef PT_LEAF_RULE
-#define PT_LEAF_RULE 0
-#endif
-__host__ __device__ inline uint32_t blas_leaf_tris(uint32_t triCount)
-{
-#if PT_LEAF_RULE == 0
-    return triCount <= 32u ? 2u : 1u;
-#elif PT_LEAF_RULE == 1
-    return 2u;
-#elif PT_LEAF_RULE == 2
-    return 3u;
-#else
-    return 1u;
-#endif
-}
+__host__ __device__ inline uint32_t blas_leaf_tris(uint32_t triCount) { return triCount <= 32u ? 2u : 1u; }
 __host__ __device__ inline bool blas_single_leaf(uint32_t triCount) { return triCount <= blas_leaf_tris(triCount); }
 
 // A traversal state is two groups: G = (child base, hits << 24 | imask) of the node whose children are being visited, and

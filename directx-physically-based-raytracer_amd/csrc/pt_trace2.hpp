@@ -243,12 +243,8 @@ PT_DEV Hit trace_closest_v2(const BlobReader<LDS>& blob, const BlobView& bv, con
 // full lanes (measured before compaction: 1.9 mesh rounds per wave at 38 % occupancy + 2.4 quad rounds at 54 %; now
 // ~128 items in 2 rounds). Same tri_test / is_better arithmetic, so the result is bit-identical to the other schedules.
 constexpr uint32_t kFlatInstances = 32;
-#ifndef PT_FLAT_STACK
-#define PT_FLAT_STACK 4
-#define PT_FLAT_ITEMS 192
-#endif
-constexpr int kStackLdsFlat = PT_FLAT_STACK;                                             // BLAS-only group stacks are shallow (one entry per level); deeper entries spill
-constexpr uint32_t kFlatItems = PT_FLAT_ITEMS;                                         // items per batch and wave
+constexpr int kStackLdsFlat = 4;                                             // BLAS-only group stacks are shallow (one entry per level); deeper entries spill
+constexpr uint32_t kFlatItems = 192;                                         // items per batch and wave
 // LDS per wave for the exchange: rays 64 x 32 B | results kFlatItems x 16 B | items kFlatItems x 4 B
 constexpr uint32_t kFlatWaveLds = 64u * 32u + kFlatItems * 16u + kFlatItems * 4u;
 constexpr uint32_t kFlatLdsFixed = (uint32_t)kStackLdsFlat * 256u * 8u + 4u * kFlatWaveLds;

@@ -1,4 +1,5 @@
-"""Writes tests/golden/ingest/fixture.gltf + scene.json. Uses struct, base64 and json ONLY -- nothing of ingest.py, so that the
+"""Writes tests/golden/ingest/fixture.gltf + scene.json, and the same model once more as a binary container: fixture.glb + scene_glb.json
+(fastgltf::Parser::loadGltf takes both, Source/GLTFHelpers.ixx:53-57). Uses struct, base64 and json ONLY -- nothing of ingest.py, so that the
 fixture cannot share a misreading with the code it checks (the expected arrays in tests/test_ingest.py are written out by hand from
 Source/GLTFHelpers.ixx:169-192, Source/Scene.ixx:199-214, Source/JSONConverters.ixx:18-26). The two files are committed; this script
 documents how the base64 payload of the .gltf was made."""
@@ -55,3 +56,20 @@ scene = {
 os.makedirs(HERE, exist_ok=True)
 json.dump(gltf, open(os.path.join(HERE, "fixture.gltf"), "w"), indent=1)
 json.dump(scene, open(os.path.join(HERE, "scene.json"), "w"), indent=1)
+
+# ---- the same asset as .glb (glTF 2.0 binary container): 12-byte header "glTF" | version 2 | total length, then chunks of
+# length | type | payload, each padded to 4 bytes: JSON (0x4E4F534A, padded with spaces) and BIN (0x004E4942, padded with zeros).
+# The one buffer has no uri: it is the BIN chunk.
+glb_json = dict(gltf)
+glb_json["buffers"] = [{"byteLength": len(blob)}]
+jbytes = json.dumps(glb_json, separators=(",", ":")).encode("utf-8")
+jbytes += b" " * (-len(jbytes) % 4)
+bbytes = blob + b"\0" * (-len(blob) % 4)
+total = 12 + 8 + len(jbytes) + 8 + len(bbytes)
+with open(os.path.join(HERE, "fixture.glb"), "wb") as f:
+    f.write(struct.pack("<4sII", b"glTF", 2, total))
+    f.write(struct.pack("<II", len(jbytes), 0x4E4F534A) + jbytes)
+    f.write(struct.pack("<II", len(bbytes), 0x004E4942) + bbytes)
+scene_glb = dict(scene)
+scene_glb["Models"] = {"m": "fixture.glb"}
+json.dump(scene_glb, open(os.path.join(HERE, "scene_glb.json"), "w"), indent=1)

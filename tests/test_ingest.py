@@ -168,3 +168,21 @@ def test_hand_written_fixture_matches_hand_derived_arrays(pkg):
     assert np.allclose(cam["RightDirection"] / np.linalg.norm(cam["RightDirection"]), (0, 0, -1), atol=1e-6)
     assert np.allclose(cam["UpDirection"] / np.linalg.norm(cam["UpDirection"]), (0, 1, 0), atol=1e-6)
     assert np.allclose(sc.scene_data["EnvironmentLightColor"], (0.1, 0.2, 0.3, 1.0))
+
+
+def test_glb_container_loads_like_the_gltf(pkg):
+    """The binary container (.glb: header, JSON chunk, BIN chunk; hand-packed by tests/golden/make_ingest_fixture.py with struct only)
+    gives the same scene as the .gltf with its base64 buffer: fastgltf::Parser::loadGltf reads both (Source/GLTFHelpers.ixx:53-57)."""
+    import dxpbrt_amd.ingest as I
+    import os
+    d = os.path.join(os.path.dirname(__file__), "golden", "ingest")
+    raw = open(os.path.join(d, "fixture.glb"), "rb").read()
+    assert raw[:4] == b"glTF" and int.from_bytes(raw[4:8], "little") == 2 and int.from_bytes(raw[8:12], "little") == len(raw) and len(raw) % 4 == 0
+    a = I.load_scene(os.path.join(d, "scene.json"), aspect=1.0)
+    b = I.load_scene(os.path.join(d, "scene_glb.json"), aspect=1.0)
+    assert len(a.nodes) == len(b.nodes) and len(a.objects) == len(b.objects)
+    for na, nb in zip(a.nodes, b.nodes):
+        for ma, mb in zip(na.meshes, nb.meshes):
+            assert ma.vertices.tobytes() == mb.vertices.tobytes() and ma.indices.tobytes() == mb.indices.tobytes()
+            assert (ma.material is None) == (mb.material is None) and (ma.material is None or ma.material.tobytes() == mb.material.tobytes())
+    assert a.object_data.tobytes() == b.object_data.tobytes() and a.instance_data.tobytes() == b.instance_data.tobytes()
