@@ -82,6 +82,7 @@ void pt_destroy(PtContext* ctx)
     }
     c.viewers.clear(); c.borrowers = 0;
     for (auto& kv : c.blas) free_blas(kv.second);
+    c.buildScratch.release();
     if (c.sceneOwner) { detach_from_owner(c); c.tlas = Tlas(); c.blobDev = nullptr; }       // views: the owner frees them
     free_tlas(c.tlas);
     if (c.heapDev) hipFree(c.heapDev);
@@ -241,7 +242,12 @@ int pt_build_bottom_level(PtContext* ctx, const PtGeometryDesc* geometries, uint
     if (s != PT_OK) return s;
     API_HIP(&c, hipSetDevice(c.device));
     Blas b;
-    hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0, c.stream, b);
+    // a static bottom level borrows the context's build buffers (grow-only: the second mesh of a scene allocates nothing but its own
+    // nodes and packets); one built for updates keeps buffers of its own
+    const bool updatable = (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0;
+    if (!updatable) std::swap(b.tree, c.buildScratch);
+    hipError_t e = build_blas_device(geometries, geometry_count, updatable, c.stream, b);
+    if (!updatable) std::swap(b.tree, c.buildScratch);
     if (e != hipSuccess) { free_blas(b); return fail_hip(&c, e, "bottom-level build"); }
     if (b.buildError || 2u * b.depth + 4u > (uint32_t)kStackSize) { free_blas(b); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level build failed: tree too deep for the traversal stack"); }
     b.geometryCount = geometry_count;
@@ -277,7 +283,10 @@ int pt_update_bottom_level(PtContext* ctx, uint64_t blas_id, const PtGeometryDes
     // not built for updates, or a different triangle count: D3D12 would reject PERFORM_UPDATE; here the structure is rebuilt under its id
     API_HIP(&c, hipStreamSynchronize(c.stream));
     Blas nb;
-    hipError_t e = build_blas_device(geometries, geometry_count, (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0 || b.updatable, c.stream, nb);
+    const bool updatable = (build_flags & PT_BUILD_FLAG_ALLOW_UPDATE) != 0 || b.updatable;
+    if (!updatable) std::swap(nb.tree, c.buildScratch);
+    hipError_t e = build_blas_device(geometries, geometry_count, updatable, c.stream, nb);
+    if (!updatable) std::swap(nb.tree, c.buildScratch);
     if (e != hipSuccess) { free_blas(nb); return fail_hip(&c, e, "bottom-level update"); }
     if (nb.buildError || 2u * nb.depth + 4u > (uint32_t)kStackSize) { free_blas(nb); return fail(&c, PT_ERROR_INVALID_ARGUMENT, "bottom-level update failed: tree too deep for the traversal stack"); }
     nb.geometryCount = geometry_count;

@@ -205,15 +205,20 @@ __device__ void instance_world_box(const InstanceRecord& ir, const float* b, flo
 {
     for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
     if (!(b[0] <= b[3])) return;                                             // empty BLAS
-    const float* M = ir.objectToWorld;
+    float M[12];                                                              // in registers: the loops below read it per vertex
+    #pragma unroll
+    for (int k = 0; k < 12; k++) M[k] = ir.objectToWorld[k];
     const float rlo[3] = { b[0], b[1], b[2] }, rhi[3] = { b[3], b[4], b[5] };
     grow_by_transformed_box(M, rlo, rhi, lo, hi);
     float tlo[3] = { INFINITY, INFINITY, INFINITY }, thi[3] = { -INFINITY, -INFINITY, -INFINITY };
-    if (ir.tris && ir.triCount <= kExactBoxTriangles) {                      // a small mesh: the vertices themselves (the tightest box there is)
-        for (uint32_t t = threadIdx.x & 63u; t < ir.triCount; t += 64u) {
-            const TriPacket tp = ir.tris[t];
+    const TriPacket* tris = ir.tris; const uint32_t triCount = ir.triCount;
+    if (tris && triCount <= kExactBoxTriangles) {                            // a small mesh: the vertices themselves (the tightest box there is)
+        for (uint32_t t = threadIdx.x & 63u; t < triCount; t += 64u) {
+            const TriPacket tp = tris[t];
             const float4 v[3] = { tp.a, tp.b, tp.c };
+            #pragma unroll
             for (int k = 0; k < 3; k++)
+                #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     const float w = M[4 * a] * v[k].x + M[4 * a + 1] * v[k].y + M[4 * a + 2] * v[k].z + M[4 * a + 3];
                     tlo[a] = fminf(tlo[a], w); thi[a] = fmaxf(thi[a], w);
@@ -225,20 +230,26 @@ __device__ void instance_world_box(const InstanceRecord& ir, const float* b, flo
         return;
     }
     if (!ir.nodes || blas_single_leaf(ir.triCount)) return;                  // a BLAS of one leaf has no node
-    const WideNode root = ir.nodes[0];
-    const uint32_t imask = root.expImask >> 24;
-    for (int s = 0; s < 8; s++) {
+    // two levels down: lane (s, t) = (lane / 8, lane % 8) takes grandchild t of child s -- or, for a leaf slot s, its lane t = 0 the child
+    // box itself -- and the wave reduces. (Every lane walking all 64 boxes by itself took 70 us for the one large mesh of a scene.)
+    {
+        const WideNode* nodes = ir.nodes;
+        const uint32_t lane = threadIdx.x & 63u, sl = lane >> 3, tl = lane & 7u;
+        const WideNode root = nodes[0];
+        const uint32_t imask = root.expImask >> 24;
         float clo[3], chi[3];
-        if (!wide_child_box(root, s, clo, chi)) continue;
-        if (imask & (1u << s)) {
-            const WideNode child = ir.nodes[root.childBase + __popc(imask & ((1u << s) - 1u))];
-            for (int t = 0; t < 8; t++) {
+        if (wide_child_box(root, (int)sl, clo, chi)) {
+            if (imask & (1u << sl)) {
+                const WideNode child = nodes[root.childBase + __popc(imask & ((1u << sl) - 1u))];
                 float glo[3], ghi[3];
-                if (!wide_child_box(child, t, glo, ghi)) continue;
-                for (int a = 0; a < 3; a++) { glo[a] = fmaxf(glo[a], clo[a]); ghi[a] = fminf(ghi[a], chi[a]); }    // inside its parent's box as well
-                if (glo[0] <= ghi[0] && glo[1] <= ghi[1] && glo[2] <= ghi[2]) grow_by_transformed_box(M, glo, ghi, tlo, thi);
-            }
-        } else grow_by_transformed_box(M, clo, chi, tlo, thi);
+                if (wide_child_box(child, (int)tl, glo, ghi)) {
+                    for (int a = 0; a < 3; a++) { glo[a] = fmaxf(glo[a], clo[a]); ghi[a] = fminf(ghi[a], chi[a]); }    // inside its parent's box as well
+                    if (glo[0] <= ghi[0] && glo[1] <= ghi[1] && glo[2] <= ghi[2]) grow_by_transformed_box(M, glo, ghi, tlo, thi);
+                }
+            } else if (tl == 0u) grow_by_transformed_box(M, clo, chi, tlo, thi);
+        }
+        for (int a = 0; a < 3; a++)
+            for (int off = 32; off > 0; off >>= 1) { tlo[a] = fminf(tlo[a], __shfl_xor(tlo[a], off)); thi[a] = fmaxf(thi[a], __shfl_xor(thi[a], off)); }
     }
     for (int a = 0; a < 3; a++) { lo[a] = fmaxf(lo[a], tlo[a]); hi[a] = fminf(hi[a], thi[a]); }
     if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
@@ -307,7 +318,7 @@ __global__ void k_karras(const uint64_t* __restrict__ keys, int n, int2* __restr
 //   C(n, 1) = min(C_leaf(n), C_internal(n)),  C_leaf(n) = A_n * P_n * c_item,  C_internal(n) = A_n * c_node + C_distribute(n, 8)
 //   C(n, i) = min(C_distribute(n, i), C(n, i - 1)),   C_distribute(n, j) = min over 0 < k < j of C(left, k) + C(right, j - k)
 // The decisions are kept (which k, leaf or node) and the collapse kernel follows them top-down.
-struct alignas(16) DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[10]; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
+struct alignas(16) DpNode { float cost[7]; uint8_t split[9]; uint8_t isLeaf; uint8_t _pad[2]; int2 children; };      // split[j], j = 2..8: k of the best distribution, 0 = "take C(n, j - 1)"
 static_assert(sizeof(DpNode) == 48, "layout");
 constexpr float kCostNode = 1.0f;
 constexpr float kCostTriangle = 0.6f;         // a triangle test against a node visit. By instruction counts (~97 against ~225) 0.4; measured 0.3 -> 0.6: C3 +3 %, C5 +3 %
@@ -401,8 +412,7 @@ __global__ void k_refit(int nleaves, const float4* __restrict__ leafLo, const fl
             const float cLeaf = P <= maxLeafItems ? A * (float)P * costItem : INFINITY;
             const float cInternal = A * kCostNode + dist[8];
             d.isLeaf = cLeaf <= cInternal; d.split[0] = d.split[1] = 0;
-            #pragma unroll
-            for (int i = 0; i < 10; i++) d._pad[i] = 0;
+            d._pad[0] = d._pad[1] = 0; d.children = ch;        // the node's children ride along: the collapse reads ONE record per node it opens
             d.cost[0] = fminf(cLeaf, cInternal);
             #pragma unroll
             for (int i = 2; i <= 7; i++) {
@@ -496,19 +506,18 @@ __device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodes
     int n = 0;
     {   // the children the cost tables chose for this node: distribute 8 roots over the two subtrees, recursively
         int sref[10]; int sbud[10]; int sp = 0;
-        const int2 c = A.children[root];
-        const int k8 = A.dp[root].split[8];
-        sref[sp] = c.y; sbud[sp++] = 8 - k8;
-        sref[sp] = c.x; sbud[sp++] = k8;
+        const DpNode dr = A.dp[root];
+        const int k8 = dr.split[8];
+        sref[sp] = dr.children.y; sbud[sp++] = 8 - k8;
+        sref[sp] = dr.children.x; sbud[sp++] = k8;
         while (sp > 0) {
-            const int m = sref[--sp], budget = sbud[sp];
-            if (m < 0 || budget == 1) {
-                if (n < 8) { refs[n] = m; leafChild[n] = m < 0 || A.dp[m].isLeaf; n++; } else *errorFlag = 1u;
-                continue;
-            }
-            const int k = A.dp[m].split[budget];
-            if (k == 0) { sref[sp] = m; sbud[sp++] = budget - 1; }
-            else { const int2 cm = A.children[m]; sref[sp] = cm.y; sbud[sp++] = budget - k; sref[sp] = cm.x; sbud[sp++] = k; }
+            const int m = sref[--sp]; int budget = sbud[sp];
+            if (m < 0) { if (n < 8) { refs[n] = m; leafChild[n] = true; n++; } else *errorFlag = 1u; continue; }
+            const DpNode dm = A.dp[m];                       // split table, leaf flag and children of the node in one 48-byte fetch
+            while (budget > 1 && dm.split[budget] == 0) budget--;                  // "take C(m, budget - 1)"
+            if (budget == 1) { if (n < 8) { refs[n] = m; leafChild[n] = dm.isLeaf != 0; n++; } else *errorFlag = 1u; continue; }
+            const int k = dm.split[budget];
+            sref[sp] = dm.children.y; sbud[sp++] = budget - k; sref[sp] = dm.children.x; sbud[sp++] = k;
         }
     }
     for (int k = 0; k < n; k++) ref_box(refs[k], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[k], hi[k]);
@@ -517,24 +526,40 @@ __device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodes
     float4 nlo, nhi;
     ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
     const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
-    int slotOf[8], childAt[8];
-    for (int s = 0; s < 8; s++) { childAt[s] = -1; slotOf[s] = -1; }
-    for (int round = 0; round < n; round++) {
-        int bc = -1, bs = -1; float bcost = INFINITY;
-        for (int c = 0; c < n; c++) {
-            if (slotOf[c] >= 0) continue;
-            float dx = 0.5f * (lo[c].x + hi[c].x) - cx, dy = 0.5f * (lo[c].y + hi[c].y) - cy, dz = 0.5f * (lo[c].z + hi[c].z) - cz;
+    // (all in registers: constant indices under full unrolling, the assignment as two bit masks and a packed slot -> child table. With
+    // arrays indexed by loop variables this was ~500 dependent scratch round trips per node: 60 us of latency on a path that a
+    // top-level rebuild of 1000 instances walks level by level)
+    float dX[8], dY[8], dZ[8];
+    #pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (c < n) {
+            dx = 0.5f * (lo[c].x + hi[c].x) - cx; dy = 0.5f * (lo[c].y + hi[c].y) - cy; dz = 0.5f * (lo[c].z + hi[c].z) - cz;
             if (!(dx == dx)) dx = 0.0f;
             if (!(dy == dy)) dy = 0.0f;
             if (!(dz == dz)) dz = 0.0f;
+        }
+        dX[c] = dx; dY[c] = dy; dZ[c] = dz;
+    }
+    uint32_t freeChild = (1u << n) - 1u, freeSlot = 0xFFu, childAtPacked = 0xFFFFFFFFu;      // 4 bits per slot: the child in it, 0xF = empty
+    for (int round = 0; round < n; round++) {
+        int bc = -1, bs = -1; float bcost = INFINITY;
+        #pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (!((freeChild >> c) & 1u)) continue;
+            #pragma unroll
             for (int s = 0; s < 8; s++) {
-                if (childAt[s] >= 0) continue;
-                const float cost = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
+                if (!((freeSlot >> s) & 1u)) continue;
+                const float cost = ((s & 4) ? -dX[c] : dX[c]) + ((s & 2) ? -dY[c] : dY[c]) + ((s & 1) ? -dZ[c] : dZ[c]);
                 if (cost < bcost || bc < 0) { bcost = cost; bc = c; bs = s; }
             }
         }
-        slotOf[bc] = bs; childAt[bs] = bc;
+        freeChild &= ~(1u << bc); freeSlot &= ~(1u << bs);
+        childAtPacked = (childAtPacked & ~(0xFu << (4 * bs))) | ((uint32_t)bc << (4 * bs));
     }
+    int childAt[8];
+    #pragma unroll
+    for (int s = 0; s < 8; s++) { const uint32_t c = (childAtPacked >> (4 * s)) & 0xFu; childAt[s] = c == 0xFu ? -1 : (int)c; }
     // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at most
     // kMaxLeafTris items: its (at most three) binary leaves are found by walking it -- they need not be neighbours in the sorted order
     uint32_t nInternal = 0, nItems = 0, imask = 0, cntItem[8], nLeaf[8]; int leafIds[8][kMaxLeafTris];
@@ -827,8 +852,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
         BVH_CHECK(hipMemcpy(exact, out.nodes, sizeof(WideNode) * hdr.nodeCount, hipMemcpyDeviceToDevice));
         hipFree(out.nodes); out.nodes = exact;
     }
-    out.updatable = allowUpdate;
-    if (!allowUpdate) out.tree.release();          // a static mesh never refits (Scene.ixx:329: no ALLOW_UPDATE)
+    out.updatable = allowUpdate;                   // a static mesh never refits (Scene.ixx:329: no ALLOW_UPDATE): its build buffers are the caller's scratch
 fail:
     if (unsorted) hipFree(unsorted);
     return err;

@@ -106,6 +106,7 @@ struct Context {
     bool heapHasTextures = false;             // any Texture2D / TextureCube descriptor: selects the TEXTURED kernel variants
 
     std::map<uint64_t, Blas> blas; uint64_t nextBlasId = 1;
+    TreeBuffers buildScratch;                         // build buffers of static bottom levels, reused from build to build (grow-only)
     Tlas tlas; bool haveTlas = false;
     Context* sceneOwner = nullptr;                    // pt_share_scene: tlas / blob below are views of that context's, never freed here
     int borrowers = 0;                                // contexts viewing THIS context's scene
