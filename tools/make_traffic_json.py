@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/final/* -> profiles/r02_* and profiles/traffic.json (HBM bytes per launch and VALU instructions per frame from the PMC
+"""gpurun_out/final/* -> profiles/r03_* and profiles/traffic.json (HBM bytes per launch and VALU instructions per frame from the PMC
 summaries, stamped with the hash of the kernel sources they were measured on: bench.py only quotes them for the same sources)."""
 import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,11 +22,14 @@ def parse(path):
 KERNEL_KEY = {"k_round": "k_round", "k_extend_stream": "k_extend", "k_extend2": "k_extend", "k_shade": "k_shade"}
 traffic = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md) + WRITE_SIZE (KB), "
                    "divided by the dispatch count, for the variant of each kernel the workload runs; valu: SQ_INSTS_VALU of all kernels of one frame. "
-                   "Sources: profiles/r02_<workload>_pmc_summary.txt. source_hash = bench.source_hash() of the kernel sources measured."}
+                   "Sources: profiles/r03_<workload>_pmc_summary.txt. source_hash = bench.source_hash() of the kernel sources measured."}
+for f in os.listdir(SRC):                    # everything that is not a per-workload file (extras of tools/collect_profiles.sh)
+    if os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err") and not f.startswith(("c2_b", "c2_k", "c2_p", "c3_", "c5_")):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r03_" + f))
 for w in ("c2", "c3", "c5"):
     for f in os.listdir(SRC):
         if f.startswith(w + "_") and os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err"):
-            shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
+            shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r03_" + f))
     pm = parse(os.path.join(SRC, w + "_pmc_summary.txt"))
     ent = {"source_hash": bench.source_hash()}
     # the kernels of the product path of this workload (the statistics frame of bench.py runs other variants: not counted)
@@ -44,7 +47,5 @@ for w in ("c2", "c3", "c5"):
     ent["valu"] = {"wave_instructions_per_frame": valu_total / frames, "frames_in_profile": frames,
                    "note": "k_gbuffer dispatches = frames; for c3 / c5 one of them is bench.py's statistics frame, whose k_shade launches are included (one frame in %d)" % frames}
     traffic[w] = ent
-for f in ("dynamic_bench.json", "c2_rehearse_collective.json"):
-    if os.path.exists(os.path.join(SRC, f)): shutil.copy(os.path.join(SRC, f), os.path.join(DST, "r02_" + f))
 json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

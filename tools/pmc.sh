@@ -9,6 +9,7 @@ mkdir -p $OUT
 run() { name=$1; shift; timeout -k 10 280 rocprofv3 --pmc "$@" -d $OUT/$name -o p --output-format csv -- python3 bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$name.json 2> $OUT/$name.err || echo "pass $name failed"; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU
 run sq2 SQ_INSTS_LDS SQ_INSTS_FLAT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
+run lanes SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
