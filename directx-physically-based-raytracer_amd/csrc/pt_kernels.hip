@@ -557,7 +557,7 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
 
 // A fresh path: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
 PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux, const uint4* __restrict__ primary,
-                        PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
+                        PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD, RoundProf* prof = nullptr)
 {
     const uint32_t pixel = p.pixel;
     const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
@@ -565,6 +565,7 @@ PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphi
     const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
     const v3 rayDir = primaryRay.d;
     const uint4 r0 = primary[3 * (size_t)pixel], r1 = primary[3 * (size_t)pixel + 1], r2 = primary[3 * (size_t)pixel + 2];
+    PT_PROF_WAIT(); PT_PROF_MARK(prof, 13);
     const float4 pos = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
     const short4 nr = make_short4((short)(r1.x & 0xFFFFu), (short)(r1.x >> 16), (short)(r1.y & 0xFFFFu), (short)(r1.y >> 16));
     const short2 fe = make_short2((short)(r1.z & 0xFFFFu), (short)(r1.z >> 16)), ge = make_short2((short)(r1.w & 0xFFFFu), (short)(r1.w >> 16));
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 #ifdef PT_ROUND_PROF
     RoundProf profData; RoundProf* prof = &profData;
-    for (int k = 0; k < 12; k++) profData.acc[k] = 0;
+    for (int k = 0; k < 16; k++) profData.acc[k] = 0;
     profData.last = __builtin_readcyclecounter();
 #else
     RoundProf* prof = nullptr;
@@ -832,14 +833,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         PathRegs p; v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
         if (local < nF) {
             p = load_path(qin, seg + (segCap - 1u - local));
-            shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD);
+            PT_PROF_WAIT(); PT_PROF_MARK(prof, 12);
+            shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD, prof);
         }
+        PT_PROF_MARK(prof, 14);
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+        PT_PROF_MARK(prof, 15);
     }
 #ifdef PT_ROUND_PROF
     // developer build only (tools/round_prof.py): per-wave section clocks (in units of 64 cycles) and item tallies through the mismatch record
     PT_PROF_MARK(prof, 8);
-    if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 12; k++) atomicAdd((unsigned int*)&counters->mismatchRay[k], k < 9 ? (prof->acc[k] >> 6) : prof->acc[k]);
+    if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 16; k++) atomicAdd((unsigned int*)&counters->mismatchRay[k], (k < 9 || k >= 12) ? (prof->acc[k] >> 6) : prof->acc[k]);
 #endif
 }
 

@@ -22,11 +22,13 @@ namespace pt {
 
 // Developer build only (-DPT_ROUND_PROF, tools/round_prof.py): wave-clock stamps between the sections of a fused round.
 #ifdef PT_ROUND_PROF
-struct RoundProf { uint64_t last; uint32_t acc[12]; };
+struct RoundProf { uint64_t last; uint32_t acc[16]; };
+#define PT_PROF_WAIT() __builtin_amdgcn_s_waitcnt(0)
 #define PT_PROF_MARK(P, i) do { if (P) { const uint64_t now_ = __builtin_readcyclecounter(); (P)->acc[i] += (uint32_t)(now_ - (P)->last); (P)->last = now_; } } while (0)
 #else
 struct RoundProf;
 #define PT_PROF_MARK(P, i) do { } while (0)
+#define PT_PROF_WAIT() do { } while (0)
 #endif
 
 struct alignas(16) InstanceT {        // 144 B = 9 x 16

@@ -19,9 +19,14 @@ for w in sys.argv[1:] or ["c2"]:
     r.render(S.graphics_settings(W, H, spp=spp, bounces=bounces, frame_index=1, ext_flags=ext)); ctx.sync()
     buf = np.zeros(16, np.float32); ctx.check(ctx.lib.pt_debug_read_mismatch(ctx.handle, buf.ctypes.data))
     m = buf.view(np.uint32)[:12].astype(np.float64)
+    f = buf.view(np.uint32)[12:16].astype(np.float64)
     c = ctx.counters()
     tot = m[:9].sum()
     print(w, "secondary rays", c.SecondaryRays, "wave tiles", int(m[11]), "items per tile %.1f" % (m[9] / max(m[11], 1)), "item rounds per tile %.2f" % (m[10] / max(m[11], 1)))
     for k in range(9):
         print("   %-18s %5.1f %%   %8.0f wave-cycles per tile" % (names[k], 100 * m[k] / tot, 64 * m[k] / max(m[11], 1)))
+    ft = f.sum()
+    if ft > 0:
+        print("   inside the fresh tiles (the profiling build waits for the loads before each stamp): state load %.0f %%, record load %.0f %%, ray + decode + scatter %.0f %%, reservation + stores %.0f %%"
+              % (100 * f[0] / ft, 100 * f[1] / ft, 100 * f[2] / ft, 100 * f[3] / ft))
     ctx.close()
