@@ -370,7 +370,9 @@ PT_DEV uint32_t block_reserve(bool alive, uint32_t* counter, uint32_t* lds)
 }
 
 // Two compactions at once (survivors -> traced region, restarts -> fresh region): one barrier sequence instead of two, and
-// the two returning atomics are issued by different waves, so their round trips (~1 us each) overlap. lds: 16 words.
+// the two returning atomics are issued by different waves, so their round trips (~1 us each) overlap. lds: 16 words; the caller hands in
+// two sets in turn, so no barrier is needed behind the last read (a wave reaches the set again only through both barriers of the call in
+// between, which every wave joins after it has finished this one): two barriers per tile instead of three, C2 +1.1 %, C3 +1.7 %.
 PT_DEV void block_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counterB, uint32_t* lds, uint32_t& slotA, uint32_t& slotB)
 {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -389,7 +391,6 @@ PT_DEV void block_reserve2(bool a, bool b, uint32_t* counterA, uint32_t* counter
     __syncthreads();
     uint32_t baseA = lds[8], baseB = lds[9];
     for (uint32_t w = 0; w < wave; w++) { baseA += lds[w]; baseB += lds[4 + w]; }
-    __syncthreads();
     slotA = baseA + (uint32_t)__popcll(ma & lt);
     slotB = baseB + (uint32_t)__popcll(mb & lt);
 }
@@ -617,7 +618,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
                                                const uint4* __restrict__ primary)
 {
-    __shared__ uint32_t lds[16];
+    __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
+    uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
     const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
             shade_traced<TEXTURED>(sv, GeometryFromAccel{ sv }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
     for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {                // fresh entries
         const uint32_t local = tile * 256u + threadIdx.x;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             p = load_path(qin, seg + (segCap - 1u - local));
             shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD);
         }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
 }
 
@@ -765,7 +767,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint32_t* countIn = A->countIn; uint32_t* countOut = A->countOut; DeviceCounters* counters = A->counters;
     const uint4* __restrict__ primary = A->primary;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t lds[16];
+    __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
+    uint32_t emits = 0;
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                        V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD, prof);
             }
             PT_PROF_MARK(prof, 6);
-            emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+            emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
             PT_PROF_MARK(prof, 7);
 #ifdef PT_ROUND_PROF
             prof->acc[11] += 1u;
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD, prof);
         }
         PT_PROF_MARK(prof, 14);
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds, toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
         PT_PROF_MARK(prof, 15);
     }
 #ifdef PT_ROUND_PROF
