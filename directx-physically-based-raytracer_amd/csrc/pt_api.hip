@@ -56,7 +56,7 @@ static void detach_from_owner(Context& c)
     c.sceneOwner = nullptr;
 }
 
-static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
+static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.idx) hipFree(b.idx); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
 static void free_tlas(Tlas& t)
 {
     void* ptrs[] = { t.nodes, t.order, t.rootBounds, t.instances, (void*)t.blasBounds };
@@ -93,6 +93,7 @@ void pt_destroy(PtContext* ctx)
     if (c.tlasHeaderHost) hipHostFree(c.tlasHeaderHost);
     if (c.tlasHeaderEvent) hipEventDestroy(c.tlasHeaderEvent);
     if (c.validateDev) hipFree(c.validateDev);
+    if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
     for (int k = 0; k < 2; k++) {
         PathQueue& q = c.queue[k];
         void* ptrs[6] = { q.s0, q.s1, q.s2, q.r0, q.r1, q.hit };
@@ -356,7 +357,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         const Blas& b = it->second;
         auto pb = pieceOf.find(descs[i].AccelerationStructure);
         if (pb == pieceOf.end()) {
-            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris });
+            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris, b.idx });
             blobNodes += b.nodeCount; blobTris += b.triCount;
             pieceIds.push_back(descs[i].AccelerationStructure);
             pb = pieceOf.emplace(descs[i].AccelerationStructure, (uint32_t)table.size() - 1).first;
@@ -369,7 +370,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
     }
     const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
-    const size_t total = instBytes + nodeBytes + triBytes + instBytes + instBytes;   // ... | leaf-order records | entry records (same size)
+    const size_t idxBytes = (size_t)blobTris * 16;
+    const size_t total = instBytes + nodeBytes + triBytes + instBytes + instBytes + idxBytes;   // ... | leaf-order records | entry records (same size) | vertex indices
     API_ARG(&c, total / 16 < 0xFFFFFFFFull, "scene too large for 32-bit blob addressing");
 
     // ---- capacities: everything is grow-only, so the rebuild of an unchanged scene layout (a dynamic frame) allocates nothing and
@@ -403,6 +405,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     for (const BlasEntry& e : table) {
         jobs.push_back(BlobCopy{ e.nodes, blob + instBytes + sizeof(WideNode) * (size_t)e.nodeBase, sizeof(WideNode) * (size_t)e.nodeCount / 16 });
         if (e.triCount) jobs.push_back(BlobCopy{ e.tris, blob + instBytes + nodeBytes + sizeof(TriPacket) * (size_t)e.triBase, sizeof(TriPacket) * (size_t)e.triCount / 16 });
+        if (e.triCount) jobs.push_back(BlobCopy{ e.idx, blob + instBytes + nodeBytes + triBytes + instBytes + instBytes + 16 * (size_t)e.triBase, (uint64_t)e.triCount });
     }
     hipError_t e = build_tlas_prepare(c.tlas, count);          // node / order arrays of the TLAS (grow-only), known before the jobs that copy them
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
@@ -451,6 +454,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     c.blob.instOff16 = 0; c.blob.nodeOff16 = (uint32_t)(instBytes / 16); c.blob.triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
     c.blob.leafInstOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
     c.blob.enterOff16 = (uint32_t)((instBytes + nodeBytes + triBytes + instBytes) / 16);
+    c.blob.idxOff16 = (uint32_t)((instBytes + nodeBytes + triBytes + instBytes + instBytes) / 16);
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;
@@ -587,8 +591,15 @@ static int validate_scene(Context& c)
         return fail(&c, PT_ERROR_INVALID_ARGUMENT, "InstanceData holds fewer records than the top level has instances");
     if (c.objectCount) {
         if (!c.validateDev) API_HIP(&c, hipMalloc((void**)&c.validateDev, sizeof(uint32_t) * 4));
+        if (c.objectCount > c.shadeGeomCap) {                // the resolved-geometry table the same kernel fills (grow-only; kernels in flight may read the old one)
+            API_HIP(&c, hipStreamSynchronize(c.stream));
+            if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
+            c.shadeGeomDev = nullptr; c.shadeGeomCap = 0;
+            API_HIP(&c, hipMalloc((void**)&c.shadeGeomDev, sizeof(ShadeGeom) * c.objectCount));
+            c.shadeGeomCap = c.objectCount;
+        }
         API_HIP(&c, hipMemsetAsync(c.validateDev, 0, sizeof(uint32_t) * 4, c.stream));
-        API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev));
+        API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev, c.shadeGeomDev));
         uint32_t r[4] = { 0, 0, 0, 0 };
         API_HIP(&c, hipMemcpyAsync(r, c.validateDev, sizeof r, hipMemcpyDeviceToHost, c.stream));
         API_HIP(&c, hipStreamSynchronize(c.stream));
@@ -623,7 +634,7 @@ static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv
                 "SceneData.EnvironmentLightTextureDescriptor is not the kind of texture IsEnvironmentLightTextureCubeMap says");
     }
     sv.accel.instances = c.tlas.instances; sv.accel.instanceCount = c.tlas.instanceCount;
-    sv.objects = c.objects; sv.objectCount = c.objectCount;
+    sv.objects = c.objects; sv.objectCount = c.objectCount; sv.shadeGeom = c.shadeGeomDev;
     sv.instanceData = c.instanceData;
     sv.heap = c.heapDev; sv.heapCount = (uint32_t)c.heapHost.size();
     sv.srgbLut = c.srgbLutDev;

@@ -71,14 +71,15 @@ __device__ __forceinline__ uint32_t load_index(const void* ib, uint32_t stride, 
 __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, const void* __restrict__ ib, uint32_t istride,
                             uint32_t nprims, uint32_t triOffset, uint32_t geomIndex, uint32_t flags,
                             TriPacket* __restrict__ tris, const uint32_t* __restrict__ slotOfPrim,
-                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ bounds)
+                            float4* __restrict__ boxLo, float4* __restrict__ boxHi, uint32_t* __restrict__ bounds, uint4* __restrict__ idxOut)
 {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     if (p < nprims) {
-        float v[3][3];
+        float v[3][3]; uint32_t vi[3];
         for (int k = 0; k < 3; k++) {
             uint32_t idx = load_index(ib, istride, 3 * p + k);
+            vi[k] = idx;
             const float* pv = (const float*)(vb + (size_t)vstride * idx);
             v[k][0] = pv[0]; v[k][1] = pv[1]; v[k][2] = pv[2];
         }
@@ -87,6 +88,7 @@ __global__ void k_tri_setup(const uint8_t* __restrict__ vb, uint32_t vstride, co
         t.b = make_float4(v[1][0], v[1][1], v[1][2], __uint_as_float(p));
         t.c = make_float4(v[2][0], v[2][1], v[2][2], __uint_as_float(flags));
         tris[slotOfPrim ? slotOfPrim[triOffset + p] : triOffset + p] = t;
+        if (idxOut) idxOut[triOffset + p] = make_uint4(vi[0], vi[1], vi[2], 0u);       // build only: a refit moves vertices, not indices
         for (int a = 0; a < 3; a++) {
             lo[a] = fminf(fminf(v[0][a], v[1][a]), v[2][a]);
             hi[a] = fmaxf(fmaxf(v[0][a], v[1][a]), v[2][a]);
@@ -725,12 +727,14 @@ __global__ void k_requantise(uint32_t nodeCount, WideNode* nodes, const int* __r
 
 // triangle packets from primitive order into node order; slotOfPrim remembers the way for refits
 __global__ void k_scatter_tris(const TriPacket* __restrict__ src, const uint32_t* __restrict__ indexSorted, const uint32_t* __restrict__ leafDst,
-                               uint32_t n, uint32_t leafSize, TriPacket* __restrict__ dst, uint32_t* __restrict__ slotOfPrim)
+                               uint32_t n, uint32_t leafSize, TriPacket* __restrict__ dst, uint32_t* __restrict__ slotOfPrim,
+                               const uint4* __restrict__ srcIdx, uint4* __restrict__ dstIdx)
 {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;          // position in Morton order
     if (m >= n) return;
     const uint32_t leaf = m / leafSize, slot = leafDst[leaf] + (m - leaf * leafSize), prim = indexSorted[m];
     dst[slot] = src[prim];
+    dstIdx[slot] = srcIdx[prim];
     if (slotOfPrim) slotOfPrim[prim] = slot;
 }
 
@@ -842,27 +846,29 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
     out.triCount = ntris;
     out.leafCount = cdiv(ntris, leafSize);
     const uint32_t capacity = wide_node_capacity(out.leafCount);
-    TriPacket* unsorted = nullptr;
+    TriPacket* unsorted = nullptr; uint4* unsortedIdx = nullptr;
     WideHeader hdr{};
     BVH_CHECK(ensure_tree_buffers(out.tree, ntris, leafSize, true));
     BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(WideNode) * capacity));
     BVH_CHECK(hipMalloc((void**)&out.tris, sizeof(TriPacket) * (ntris ? ntris : 1)));
+    BVH_CHECK(hipMalloc((void**)&out.idx, sizeof(uint4) * (ntris ? ntris : 1)));
     BVH_CHECK(hipMalloc((void**)&out.rootBounds, sizeof(float) * 8));
     if (ntris) {
         BVH_CHECK(hipMalloc((void**)&unsorted, sizeof(TriPacket) * ntris));
+        BVH_CHECK(hipMalloc((void**)&unsortedIdx, sizeof(uint4) * ntris));
         k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
         uint32_t off = 0;
         for (uint32_t g = 0; g < ngeoms; g++) {
             uint32_t np = geoms[g].IndexCount / 3;
             if (np) k_tri_setup<<<cdiv(np, 256), 256, 0, stream>>>((const uint8_t*)geoms[g].VertexBuffer, geoms[g].VertexStride,
                                                                    geoms[g].IndexBuffer, geoms[g].IndexStride, np, off, g, geoms[g].Flags,
-                                                                   unsorted, nullptr, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
+                                                                   unsorted, nullptr, out.tree.boxLo, out.tree.boxHi, out.tree.bounds, unsortedIdx);
             off += np;
         }
         BVH_CHECK(hipGetLastError());
     }
     BVH_CHECK(build_wide_tree(out.tree, ntris, leafSize, kMaxLeafTris, kCostTriangle, true, false, out.nodes, out.rootBounds, stream));
-    if (ntris) k_scatter_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, out.tree.indexSorted, out.tree.leafDst, ntris, leafSize, out.tris, out.tree.slotOfPrim);
+    if (ntris) k_scatter_tris<<<cdiv(ntris, 256), 256, 0, stream>>>(unsorted, out.tree.indexSorted, out.tree.leafDst, ntris, leafSize, out.tris, out.tree.slotOfPrim, unsortedIdx, out.idx);
     BVH_CHECK(hipMemcpyAsync(&hdr, out.tree.header, sizeof hdr, hipMemcpyDeviceToHost, stream));
     BVH_CHECK(hipStreamSynchronize(stream));     // build is a load-time operation (reference: CommandList::End after the BLAS build, Scene.ixx:184-188)
     out.nodeCount = hdr.nodeCount; out.depth = hdr.depth; out.buildError = hdr.error != 0;
@@ -875,6 +881,7 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
     out.updatable = allowUpdate;                   // a static mesh never refits (Scene.ixx:329: no ALLOW_UPDATE): its build buffers are the caller's scratch
 fail:
     if (unsorted) hipFree(unsorted);
+    if (unsortedIdx) hipFree(unsortedIdx);
     return err;
 }
 
@@ -888,7 +895,7 @@ hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
         uint32_t np = geoms[g].IndexCount / 3;
         if (np) k_tri_setup<<<cdiv(np, 256), 256, 0, stream>>>((const uint8_t*)geoms[g].VertexBuffer, geoms[g].VertexStride,
                                                                geoms[g].IndexBuffer, geoms[g].IndexStride, np, off, g, geoms[g].Flags,
-                                                               b.tris, b.tree.slotOfPrim, b.tree.boxLo, b.tree.boxHi, nullptr);
+                                                               b.tris, b.tree.slotOfPrim, b.tree.boxLo, b.tree.boxHi, nullptr, nullptr);
         off += np;
     }
     k_leaves<<<cdiv(b.leafCount, 256), 256, 0, stream>>>(nullptr, b.tree.indexSorted, b.tree.boxLo, b.tree.boxHi, b.triCount, b.leafCount, leafSize,

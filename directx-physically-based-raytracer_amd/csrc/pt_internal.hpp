@@ -37,6 +37,7 @@ inline uint32_t wide_node_capacity(uint32_t nleaves) { return nleaves + 1u; }
 struct Blas {
     WideNode* nodes = nullptr;
     TriPacket* tris = nullptr;               // node order: the triangles of a node's leaf slots are contiguous
+    uint4* idx = nullptr;                    // the three vertex indices of every triangle, same order (hit reconstruction: no index-buffer hop)
     float* rootBounds = nullptr;             // device: lo.xyz hi.xyz
     uint32_t triCount = 0, leafCount = 0, nodeCount = 0, depth = 0, geometryCount = 0;
     bool buildError = false, updatable = false;
@@ -56,13 +57,19 @@ struct Tlas {
 
 // host -> device inputs of a top-level build, one upload per build
 struct InstanceSource { float transform[12]; uint32_t instanceID, mask, blasSlot, _pad; };
-struct BlasEntry { const WideNode* nodes; const TriPacket* tris; const float* rootBounds; uint32_t triCount, nodeCount, nodeBase, triBase; };
+struct BlasEntry { const WideNode* nodes; const TriPacket* tris; const float* rootBounds; uint32_t triCount, nodeCount, nodeBase, triBase; const uint4* idx; };
 struct BlobCopy { const void* src; void* dst; uint64_t n16; };
+
+// What hit reconstruction needs of an object's geometry, resolved once per change of (ObjectData, heap) by the validation kernel: the
+// object record -> descriptor table -> buffer chain of the reference (RaytracingHelpers.hlsli:82-85) is one fetch here.
+struct alignas(16) ShadeGeom { const uint8_t* vb; const void* ib; uint32_t stride, ibStride, nOff, tOff; };   // nOff / tOff = ~0u: attribute absent
+static_assert(sizeof(ShadeGeom) == 32, "layout");
 
 // everything a render kernel needs about the scene, passed by value as a kernel argument
 struct SceneView {
     AccelView accel;
     const PtObjectData* objects;
+    const ShadeGeom* shadeGeom;              // [objectCount]
     const PtInstanceData* instanceData;
     const HeapEntry* heap;
     const float* srgbLut;                    // 256-entry sRGB -> linear table (device)
@@ -121,6 +128,7 @@ struct Context {
     size_t blobCapacity = 0;
     uint32_t tlasValidatedCount = ~0u, persistentGrid = 0;
     uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
+    ShadeGeom* shadeGeomDev = nullptr; uint32_t shadeGeomCap = 0;
     bool validated = false; uint32_t* validateDev = nullptr;   // descriptor / index validation of the scene inputs (pt_api.hip make_views)
     const void* validatedObjects = nullptr; uint32_t validatedObjectCount = 0;
 
@@ -172,7 +180,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
 hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
 hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap);
-hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out);
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 

@@ -97,18 +97,7 @@ PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)     
 // What hit reconstruction needs from the acceleration structure: the instance's two transforms, its InstanceID and the
 // triangle packet. Two sources with identical contents: the TLAS / BLAS arrays (k_gbuffer, k_shade) or the compact scene
 // blob, which the fused round kernel already holds in LDS for small scenes (two dependent HBM round trips less per hit).
-struct HitGeometry { float M[12], W[12]; uint32_t instanceID; TriPacket tp; };
-
-PT_DEV HitGeometry load_hit_geometry(const SceneView& sv, uint32_t inst, uint32_t triSlot)
-{
-    const InstanceRecord* ir = &sv.accel.instances[inst];
-    HitGeometry g;
-    g.tp = ir->tris[triSlot];
-    g.instanceID = ir->instanceID;
-    #pragma unroll
-    for (int k = 0; k < 12; k++) { g.M[k] = ir->objectToWorld[k]; g.W[k] = ir->worldToObject[k]; }
-    return g;
-}
+struct HitGeometry { float M[12], W[12]; uint32_t instanceID; TriPacket tp; uint32_t vi[3]; };      // vi: the triangle's vertex indices
 
 template <bool LDS>
 PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView& bv, uint32_t inst, uint32_t triSlot)
@@ -118,7 +107,9 @@ PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView
     const f4v m0 = blob.ld(ia + 6), m1 = blob.ld(ia + 7), m2 = blob.ld(ia + 8);
     const uint32_t ta = bv.triOff16 + (__float_as_uint(b1.w) + triSlot) * kTri16;
     const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
+    const f4v ix = blob.ld(bv.idxOff16 + __float_as_uint(b1.w) + triSlot);
     HitGeometry g;
+    g.vi[0] = __float_as_uint(ix.x); g.vi[1] = __float_as_uint(ix.y); g.vi[2] = __float_as_uint(ix.z);
     g.tp.a = make_float4(pa.x, pa.y, pa.z, pa.w); g.tp.b = make_float4(pb.x, pb.y, pb.z, pb.w); g.tp.c = make_float4(pc.x, pc.y, pc.z, pc.w);
     g.instanceID = __float_as_uint(mk.z);
     g.W[0] = w0.x; g.W[1] = w0.y; g.W[2] = w0.z; g.W[3] = w0.w; g.W[4] = w1.x; g.W[5] = w1.y; g.W[6] = w1.z; g.W[7] = w1.w;
@@ -139,16 +130,16 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
     const float* M = hg.M; const float* W = hg.W;
     safe_triangle_spawn_point(V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), bu, bv, M, W,
                               h.ObjectPosition, h.Position, h.FlatNormal, h.PositionOffset);
-    const PtObjectData* od = &sv.objects[h.ObjectIndex];
-    const uint32_t nOff = od->VertexDesc.AttributeOffsets.Normal;
+    // Vertex attributes: the object's resolved geometry (ONE fetch: buffer pointers, stride, offsets -- instead of object record ->
+    // descriptor table) and the triangle's vertex indices, which came with the hit geometry (no index-buffer fetch): two dependent
+    // loads from hit to normals where the reference's chain (RaytracingHelpers.hlsli:82-105) has four.
+    const ShadeGeom sg = sv.shadeGeom[h.ObjectIndex];
+    const uint32_t nOff = sg.nOff;
     if (nOff != ~0u) {                                     // HitInfo.hlsli:52-65
-        const HeapEntry vb = sv.heap[od->MeshDescriptors.Vertices], ib = sv.heap[od->MeshDescriptors.Indices];
-        const uint32_t stride = od->VertexDesc.Stride;
         v3 nrm[3];
         #pragma unroll
         for (int k = 0; k < 3; k++) {
-            uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
-            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + nOff);
+            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>(sg.vb + (size_t)sg.stride * hg.vi[k] + nOff);
             nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
         v3 n = interp3(nrm[0], nrm[1], nrm[2], bu, bv);          // Vertex::Interpolate, Vertex.hlsli:63-72
@@ -162,30 +153,22 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
     if (!h.IsFrontFace) h.ShadingNormal = -h.ShadingNormal;
     h.Tangent = V3(0.0f, 0.0f, 0.0f);                      // RaytracingHelpers.hlsli:115-122
     if (!TEXTURED) return;
-    const uint32_t tOff = od->VertexDesc.AttributeOffsets.Tangent;
+    const uint32_t tOff = sg.tOff;
     if (tOff != ~0u) {
-        const HeapEntry vb = sv.heap[od->MeshDescriptors.Vertices], ib = sv.heap[od->MeshDescriptors.Indices];
-        const uint32_t stride = od->VertexDesc.Stride;
         v3 tg[3];
         #pragma unroll
         for (int k = 0; k < 3; k++) {
-            uint32_t idx = load_index_dev(ib.ptr, ib.stride, 3 * prim + k);
-            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>((const uint8_t*)vb.ptr + (size_t)stride * idx + tOff);
+            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>(sg.vb + (size_t)sg.stride * hg.vi[k] + tOff);
             tg[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
         }
         const v3 t = interp3(tg[0], tg[1], tg[2], bu, bv);
         h.Tangent = normalize(V3(sop3(M[0], t.x, M[1], t.y, M[2], t.z), sop3(M[4], t.x, M[5], t.y, M[6], t.z), sop3(M[8], t.x, M[9], t.y, M[10], t.z)));
     }
+    const PtObjectData* od = &sv.objects[h.ObjectIndex];
     get_texture_coordinates(od, sv.heap, prim, bu, bv, h.TextureCoordinates);      // :124-130
 }
 
 PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
-
-template <bool TEXTURED>
-PT_DEV void reconstruct_hit(const SceneView& sv, uint32_t inst, uint32_t triSlot, float bu, float bv, v3 rayDir, SurfaceHit& h)
-{
-    reconstruct_hit<TEXTURED>(sv, load_hit_geometry(sv, inst, triSlot), inst, bu, bv, rayDir, h);
-}
 
 template <bool TEXTURED>
 PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
@@ -526,10 +509,6 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const
 
 // ---- the bodies of k_shade, shared with the fused round kernel k_round ----------------------------------------
 // A traced path at its hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304. hit = (instance, triangle slot, u, v).
-struct GeometryFromAccel {                                   // hit geometry out of the TLAS / BLAS arrays
-    const SceneView& sv;
-    PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry(sv, inst, slot); }
-};
 template <bool LDS> struct GeometryFromBlob {                // ... out of the scene blob (LDS-resident when LDS)
     const BlobReader<LDS>& blob; const BlobView& bv;
     PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry<LDS>(blob, bv, inst, slot); }
@@ -616,8 +595,9 @@ PT_DEV void emit_tile(const PathQueue& qout, uint32_t seg, uint32_t segCap, uint
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
-                                               const uint4* __restrict__ primary)
+                                               const uint4* __restrict__ primary, BlobView bv)
 {
+    BlobReader<false> blob; blob.p = bv.base;
     __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
     uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
@@ -634,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             p = load_path(qin, i);
             const uint4 hr = qin.hit[i];
             const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
-            shade_traced<TEXTURED>(sv, GeometryFromAccel{ sv }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
+            shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
@@ -1125,7 +1105,8 @@ hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8
 
 // scene-input validation (pt_api.hip validate_scene): every descriptor index ObjectData carries must name a heap entry of the
 // right kind. out: error member (1 Vertices, 2 Indices, 3 MotionVectors, 4 TextureMapInfo) | object | descriptor | 1 = wrong kind
-__global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uint32_t count, const HeapEntry* __restrict__ heap, uint32_t heapCount, uint32_t* out)
+__global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uint32_t count, const HeapEntry* __restrict__ heap, uint32_t heapCount, uint32_t* out,
+                                   ShadeGeom* __restrict__ shadeGeom)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -1144,11 +1125,18 @@ __global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uin
         else if (heap[d].kind != kKindTexture2D) { err = 4; desc = d; kind = 1; }
     }
     if (err && atomicCAS(&out[0], 0u, err) == 0u) { out[1] = i; out[2] = desc; out[3] = kind; }
+    // the resolved geometry of the object (ShadeGeom): an object without vertex / index buffers has no vertex attributes to fetch
+    ShadeGeom sg; sg.vb = nullptr; sg.ib = nullptr; sg.stride = 0; sg.ibStride = 0; sg.nOff = ~0u; sg.tOff = ~0u;
+    if (!err && md[0] != ~0u && md[1] != ~0u) {
+        sg.vb = (const uint8_t*)heap[md[0]].ptr; sg.ib = heap[md[1]].ptr; sg.stride = od->VertexDesc.Stride; sg.ibStride = heap[md[1]].stride;
+        sg.nOff = od->VertexDesc.AttributeOffsets.Normal; sg.tOff = od->VertexDesc.AttributeOffsets.Tangent;
+    }
+    shadeGeom[i] = sg;
 }
 
-hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out)
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom)
 {
-    if (count) k_validate_objects<<<(count + 255) / 256, 256, 0, stream>>>(objects, count, heap, heapCount, out);
+    if (count) k_validate_objects<<<(count + 255) / 256, 256, 0, stream>>>(objects, count, heap, heapCount, out, shadeGeom);
     return hipGetLastError();
 }
 
@@ -1285,8 +1273,8 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
                 uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
                 timing_begin(c, c.evShade, c.nShade);
-                if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
-                else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
+                if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords, c.blob);
+                else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords, c.blob);
                 timing_end(c, c.evShade, c.nShade); c.nShade++;
                 if (r == rounds) break;
                 timing_begin(c, c.evExtend, c.nExtend);
@@ -1323,8 +1311,8 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
-        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords);
+        if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords, c.blob);
+        else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, cin, cout, c.primaryRecords, c.blob);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);

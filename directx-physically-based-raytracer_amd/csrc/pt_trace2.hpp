@@ -43,6 +43,7 @@ static_assert(sizeof(InstanceT) == 144, "layout");
 struct BlobView {
     const f4v* base;                   // device pointer to the blob
     uint32_t instOff16, nodeOff16, triOff16, leafInstOff16;   // section starts in 16-byte units
+    uint32_t idxOff16;                 // vertex indices: one unit per triangle packet, same numbering (i0, i1, i2, -)
     uint32_t enterOff16;               // entry records (9 units per instance, TLAS leaf order): worldToObject | bases, count, mask, index | the BLAS's root node
     uint32_t instCount, nodeCount, triCount;
     uint32_t bytes;                    // whole blob

@@ -272,7 +272,9 @@ int  pt_share_scene(PtContext* ctx, PtContext* source);
  * ------------------------------------------------------------------------------------------ */
 int  pt_set_camera(PtContext* ctx, const PtCamera* camera);                          /* host struct, copied */
 int  pt_set_scene_data(PtContext* ctx, const PtSceneData* scene_data);               /* host struct, copied */
-int  pt_set_object_data(PtContext* ctx, const PtObjectData* device_objects, uint32_t count);     /* device array, referenced */
+/* device array, referenced. Material and TextureMapInfoArray are read at every hit; VertexDesc and MeshDescriptors are resolved (and
+ * checked against the descriptor heap) when the binding -- pointer or count --, the heap or the top level changes: rebind after rewriting them in place. */
+int  pt_set_object_data(PtContext* ctx, const PtObjectData* device_objects, uint32_t count);
 int  pt_set_instance_data(PtContext* ctx, const PtInstanceData* device_instances, uint32_t count); /* device array, referenced */
 
 /* Multi-GPU framebuffer sharding (not a reference feature). The frame is cut into
