@@ -1,8 +1,10 @@
 """Row-band framebuffer sharding across ranks (the multi-GPU design of SURVEY.md 8e; not a reference feature).
 
 Band b (BandHeight rows) belongs to rank b % world; a rank stores its bands contiguously. The same mapping
-is implemented on the device by pt_set_sharding / pt_deinterleave_bands (include/ptamd.h); this module is the
-host-side statement of it, used by bench.py and by the CPU tests of the N > 1 path.
+is implemented in the library by pt_set_sharding / pt_gather_bands / pt_gather_plan (include/ptamd.h, csrc/pt_comm.hip:
+the RCCL exchange that bench.py and the C++ host use); this module is the host-side statement of it, used by the tests:
+the expectations of the GPU sharding tests, the check of pt_gather_plan, and the 2-process gloo test of the N > 1 path,
+where gather_to_root stands in for the RCCL exchange.
 """
 import numpy as np
 
