@@ -92,6 +92,10 @@ struct PathQueue {
     uint4*  hit;     // instance | triangle slot in the BLAS | u bits | v bits      (instance ~0u = miss)
 };
 
+// Queue geometry (pt_kernels.hip "wavefront path tracer"): the path queue is cut into kSubQueues independent sub-queues
+constexpr uint32_t kSubQueues = 32;
+constexpr uint32_t kCountStride = 3u * kSubQueues;      // per round: entries traced | fresh | cursor of the streaming form, one word per sub-queue
+
 struct FrameConstants { PtCamera cam; PtSceneData sd; PtGraphicsSettings gs; };
 struct RoundArgs;
 
@@ -173,6 +177,12 @@ __host__ __device__ void invert_3x4(const float m[12], float out[12]);
 
 // pt_skin.hip
 hipError_t launch_skin(hipStream_t stream, const void* skeletal, const float* transforms, void* vertices, void* motion, uint32_t count);
+
+// pt_stream.hip
+hipError_t launch_shade(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, const PathQueue& qin, const PathQueue& qout, float2* aux,
+                        uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid);
+hipError_t launch_extend_stream(Context& c, const AlphaContext& ac, const PathQueue& q, uint32_t segCap, const uint32_t* count, uint32_t* cursor,
+                                uint32_t grid, bool stats, bool writeT);
 
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);

@@ -11,9 +11,10 @@ make -s -C $CSRC
 while [ $# -gt 1 ]; do
   name=$1; defs=$2; shift 2
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_kernels.hip -o $OUT/pt_kernels_$name.o &&
+    /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_stream.hip -o $OUT/pt_stream_$name.o &&
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_bvh.hip -o $OUT/pt_bvh_$name.o &&
     /opt/rocm/bin/hipcc $FLAGS $defs -c $CSRC/pt_api.hip -o $OUT/pt_api_$name.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libptamd_$name.so $OUT/pt_api_$name.o $OUT/pt_bvh_$name.o $OUT/pt_kernels_$name.o $CSRC/pt_skin.o $CSRC/pt_comm.o -ldl &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libptamd_$name.so $OUT/pt_api_$name.o $OUT/pt_bvh_$name.o $OUT/pt_kernels_$name.o $OUT/pt_stream_$name.o $CSRC/pt_skin.o $CSRC/pt_comm.o -ldl &&
     echo built $name ) &
   if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi
 done
