@@ -59,7 +59,7 @@ static void detach_from_owner(Context& c)
 static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.idx) hipFree(b.idx); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
 static void free_tlas(Tlas& t)
 {
-    void* ptrs[] = { t.nodes, t.order, t.rootBounds, t.instances, (void*)t.blasBounds };
+    void* ptrs[] = { t.nodes, t.rootBounds, t.instances, (void*)t.blasBounds };
     for (void* p : ptrs) if (p) hipFree(p);
     t.tree.release();
     t = Tlas();
@@ -441,11 +441,10 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     const BlobCopy* dJobs = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + jobsOff);
 
     // ---- device side, all in stream order
-    e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.stream);
+    e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.tlas.tree.bounds, c.stream);
     if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
-    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas.tree.boxLo, c.tlas.tree.boxHi, dTable, count, (InstanceT*)blob, c.tlas.order,
-                                                 (InstanceT*)(blob + instBytes + nodeBytes + triBytes), dJobs, (uint32_t)jobs.size(),
-                                                 (const f4v*)(blob + instBytes), (f4v*)(blob + instBytes + nodeBytes + triBytes + instBytes), c.stream);
+    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas, dTable, count, (InstanceT*)blob, (InstanceT*)(blob + instBytes + nodeBytes + triBytes),
+                                                 dJobs, (uint32_t)jobs.size(), (f4v*)(blob + instBytes + nodeBytes + triBytes + instBytes), c.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipEventRecord(c.tlasHeaderEvent, c.stream);
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");

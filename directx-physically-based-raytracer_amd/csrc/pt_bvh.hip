@@ -518,124 +518,226 @@ struct CollapseArgs {
     WideHeader* header;
 };
 
-// One wide node: w is its index, binaryRootOf[w] the binary node it grows from. Follows the cost tables down to (at most) eight children,
-// deals them to octant-ordered slots, reserves its internal children (consecutive node indices) and its leaf items from the two counters,
-// quantises, writes the node and queues the children (binaryRootOf of their indices).
-__device__ void collapse_node(const CollapseArgs& A, uint32_t w, uint32_t* nodesCtr, uint32_t* itemsCtr, uint32_t* errorFlag)
+// Eight consecutive lanes share one wide node (a wave holds eight groups, all of them in the same code).
+__device__ __forceinline__ uint32_t group_ballot(bool p) { return (uint32_t)(__builtin_amdgcn_ballot_w64(p) >> (threadIdx.x & 56u)) & 0xFFu; }
+__device__ __forceinline__ uint32_t group_or(uint32_t v) { v |= __shfl_xor(v, 1, 8); v |= __shfl_xor(v, 2, 8); v |= __shfl_xor(v, 4, 8); return v; }
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, uint32_t r)      // position of the r-th set bit of an 8-bit mask, 8 if there is none
 {
-    int refs[8]; float4 lo[8], hi[8]; bool leafChild[8];
-    const int root = A.binaryRootOf[w];
-    int n = 0;
-    {   // the children the cost tables chose for this node: distribute 8 roots over the two subtrees, recursively
-        int sref[10]; int sbud[10]; int sp = 0;
-        const DpNode dr = A.dp[root];
-        const int k8 = dr.split[8];
-        sref[sp] = dr.children.y; sbud[sp++] = 8 - k8;
-        sref[sp] = dr.children.x; sbud[sp++] = k8;
-        while (sp > 0) {
-            const int m = sref[--sp]; int budget = sbud[sp];
-            if (m < 0) { if (n < 8) { refs[n] = m; leafChild[n] = true; n++; } else *errorFlag = 1u; continue; }
-            const DpNode dm = A.dp[m];                       // split table, leaf flag and children of the node in one 48-byte fetch
-            while (budget > 1 && dm.split[budget] == 0) budget--;                  // "take C(m, budget - 1)"
-            if (budget == 1) { if (n < 8) { refs[n] = m; leafChild[n] = dm.isLeaf != 0; n++; } else *errorFlag = 1u; continue; }
-            const int k = dm.split[budget];
-            sref[sp] = dm.children.y; sbud[sp++] = budget - k; sref[sp] = dm.children.x; sbud[sp++] = k;
-        }
-    }
-    for (int k = 0; k < n; k++) ref_box(refs[k], A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo[k], hi[k]);
-    // slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2,
-    // greedy instead of the auction: repeatedly the cheapest unassigned (child, slot) pair)
-    float4 nlo, nhi;
-    ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
-    const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
-    // (all in registers: constant indices under full unrolling, the assignment as two bit masks and a packed slot -> child table. With
-    // arrays indexed by loop variables this was ~500 dependent scratch round trips per node: 60 us of latency on a path that a
-    // top-level rebuild of 1000 instances walks level by level)
-    float dX[8], dY[8], dZ[8];
     #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-        if (c < n) {
-            dx = 0.5f * (lo[c].x + hi[c].x) - cx; dy = 0.5f * (lo[c].y + hi[c].y) - cy; dz = 0.5f * (lo[c].z + hi[c].z) - cz;
-            if (!(dx == dx)) dx = 0.0f;
-            if (!(dy == dy)) dy = 0.0f;
-            if (!(dz == dz)) dz = 0.0f;
+    for (uint32_t i = 0; i < 7; i++) if (i < r) m &= m - 1u;
+    return m ? (uint32_t)__ffs(m) - 1u : 8u;
+}
+
+// One wide node per GROUP of eight lanes: w is its index, binaryRootOf[w] the binary node it grows from. The group follows the cost tables
+// down to (at most) eight children, one per lane, deals them to octant-ordered slots, reserves the internal children (consecutive node
+// indices) and the leaf items from the two counters, quantises, writes the node and queues the children (binaryRootOf of their indices).
+// One thread did all of this until round 3, ~45 us of dependent loads and ~3000 serial instructions per node -- and a top-level rebuild walks
+// its tree level by level, so a dynamic frame waited 4 x 45 us. Here the frontier of the cost-table walk is expanded by all its entries at
+// once (<= 4 rounds of loads for a balanced choice instead of 15 loads in a row), every child's box, leaf walk and quantisation runs in its
+// own lane, and the greedy slot assignment is eight lane-local scans + a three-step group minimum per round. Every lane of the wave must
+// call it (inactive groups pass active = false): the group operations are wave operations.
+// The result is the one the serial form produced: children are ranked in left-to-right order of the binary tree (the rank breaks cost ties,
+// as the child index did), and the float expressions are the same.
+__device__ void collapse_node(const CollapseArgs& A, uint32_t w, bool active, uint32_t* nodesCtr, uint32_t* itemsCtr, uint32_t* errorFlag)
+{
+    const uint32_t sub = threadIdx.x & 7u;
+    const int root = active ? A.binaryRootOf[w] : 0;
+    // 1. the children the cost tables chose: (binary node, roots it may use) entries, one per lane; an entry with more than one root to
+    // spend splits in two as its table says, the right half moves to a free lane. key = the entry's path (bit 7 - d set: right at depth d),
+    // so that ascending keys are the left-to-right order.
+    int ref = root, budget = (active && sub == 0) ? 8 : 0;
+    uint32_t key = 0, depth = 0;
+    bool settled = false, leafChild = false;
+    for (uint32_t pass = 0; pass < 9; pass++) {
+        const bool open = budget > 0 && !settled;
+        if (!__builtin_amdgcn_ballot_w64(open)) break;
+        bool splits = false; int otherRef = 0, otherBudget = 0;
+        if (open) {
+            if (ref < 0) { settled = true; leafChild = true; }
+            else {
+                const uint4* rec = (const uint4*)&A.dp[ref];           // split[] sits in bytes 28..36, isLeaf in 37, the children in 40..47
+                const uint4 r1 = rec[1], r2 = rec[2];
+                auto split = [&](int j) -> int { return (int)((j < 4 ? r1.w >> (8 * j) : j < 8 ? r2.x >> (8 * (j - 4)) : r2.y) & 0xFFu); };
+                if (pass) while (budget > 1 && split(budget) == 0) budget--;        // "take C(m, budget - 1)"; the root spends its eight as split[8] says
+                if (budget == 1) { settled = true; leafChild = ((r2.y >> 8) & 0xFFu) != 0u; }
+                else {
+                    const int k = split(budget);
+                    splits = true; otherRef = (int)r2.w; otherBudget = budget - k;
+                    ref = (int)r2.z; budget = k;
+                }
+            }
         }
-        dX[c] = dx; dY[c] = dy; dZ[c] = dz;
+        const uint32_t splitMask = group_ballot(splits), freeMask = group_ballot(budget == 0);
+        const uint32_t from = nth_set_bit(splitMask, __popc(freeMask & ((1u << sub) - 1u)));      // the r-th free lane takes from the r-th splitting one
+        const uint32_t otherTag = (key | (1u << (7u - depth))) | ((depth + 1u) << 8);
+        const int gotRef = __shfl(otherRef, (int)(from & 7u), 8), gotBudget = __shfl(otherBudget, (int)(from & 7u), 8);
+        const uint32_t gotTag = __shfl(otherTag, (int)(from & 7u), 8);
+        if (splits) depth++;
+        if (budget == 0 && from < 8u) { ref = gotRef; budget = gotBudget; key = gotTag & 0xFFu; depth = gotTag >> 8; }
     }
-    uint32_t freeChild = (1u << n) - 1u, freeSlot = 0xFFu, childAtPacked = 0xFFFFFFFFu;      // 4 bits per slot: the child in it, 0xF = empty
-    for (int round = 0; round < n; round++) {
-        int bc = -1, bs = -1; float bcost = INFINITY;
-        #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            if (!((freeChild >> c) & 1u)) continue;
+    const bool occupied = budget > 0;
+    if (occupied && !settled) *errorFlag = 1u;                               // cannot happen: eight roots are spent after seven splits
+    uint32_t rank = 0;
+    #pragma unroll
+    for (int j = 0; j < 8; j++) { const uint32_t kj = __shfl(occupied ? key : 0x100u, j, 8); rank += (occupied && kj < key) ? 1u : 0u; }
+    const uint32_t n = __popc(group_ballot(occupied));
+
+    // 2. boxes
+    float4 lo = make_float4(0, 0, 0, 0), hi = lo, nlo, nhi;
+    if (occupied) ref_box(ref, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, lo, hi);
+    ref_box(root, A.leafLo, A.leafHi, A.nodeLo, A.nodeHi, nlo, nhi);
+
+    // 3. slots: child c goes where "slot xor octant" visits it in front-to-back order for rays of that octant (paper 3.2, greedy instead of
+    // the auction: repeatedly the cheapest unassigned (child, slot) pair, the first such pair in (child, slot) order)
+    float dX = 0.0f, dY = 0.0f, dZ = 0.0f;
+    if (occupied) {
+        const float cx = 0.5f * (nlo.x + nhi.x), cy = 0.5f * (nlo.y + nhi.y), cz = 0.5f * (nlo.z + nhi.z);
+        dX = 0.5f * (lo.x + hi.x) - cx; dY = 0.5f * (lo.y + hi.y) - cy; dZ = 0.5f * (lo.z + hi.z) - cz;
+        if (!(dX == dX)) dX = 0.0f;
+        if (!(dY == dY)) dY = 0.0f;
+        if (!(dZ == dZ)) dZ = 0.0f;
+    }
+    uint32_t freeSlot = 0xFFu, mySlot = 0; bool assigned = false;
+    for (uint32_t round = 0; round < 8; round++) {
+        if (!__builtin_amdgcn_ballot_w64(round < n)) break;
+        float bcost = INFINITY; int bs = -1;
+        if (occupied && !assigned) {
             #pragma unroll
             for (int s = 0; s < 8; s++) {
                 if (!((freeSlot >> s) & 1u)) continue;
-                const float cost = ((s & 4) ? -dX[c] : dX[c]) + ((s & 2) ? -dY[c] : dY[c]) + ((s & 1) ? -dZ[c] : dZ[c]);
-                if (cost < bcost || bc < 0) { bcost = cost; bc = c; bs = s; }
+                const float cost = ((s & 4) ? -dX : dX) + ((s & 2) ? -dY : dY) + ((s & 1) ? -dZ : dZ);
+                if (cost < bcost || bs < 0) { bcost = cost; bs = s; }
             }
         }
-        freeChild &= ~(1u << bc); freeSlot &= ~(1u << bs);
-        childAtPacked = (childAtPacked & ~(0xFu << (4 * bs))) | ((uint32_t)bc << (4 * bs));
+        uint32_t tag = bs >= 0 ? (rank << 8) | ((uint32_t)bs << 4) | sub : 0xFFFFFFFFu;
+        #pragma unroll
+        for (int x = 1; x < 8; x <<= 1) {
+            const float oc = __shfl_xor(bcost, x, 8); const uint32_t ot = __shfl_xor(tag, x, 8);
+            if (ot != 0xFFFFFFFFu && (tag == 0xFFFFFFFFu || oc < bcost || (oc == bcost && ot < tag))) { bcost = oc; tag = ot; }
+        }
+        if (tag != 0xFFFFFFFFu) {
+            const uint32_t ws = (tag >> 4) & 0xFu;
+            if ((tag & 0xFu) == sub) { assigned = true; mySlot = ws; }
+            freeSlot &= ~(1u << ws);
+        }
     }
-    int childAt[8];
+    if (!occupied) mySlot = nth_set_bit(freeSlot, __popc(group_ballot(!occupied) & ((1u << sub) - 1u))) & 7u;     // the empty slots go to the idle lanes
+
+    // 4. a leaf child is a leaf of the binary tree or a whole subtree of at most kMaxLeafTris items: its (at most three) binary leaves are found
+    // by walking it -- they need not be neighbours in the sorted order
+    const bool internalChild = occupied && !leafChild;
+    int leafId[kMaxLeafTris] = { 0, 0, 0 }; uint32_t nl = 0, cnt = 0;
+    if (occupied && leafChild) {
+        auto add = [&](int m) {
+            if (m >= 0) { *errorFlag = 1u; return; }                        // deeper than three leaves can be
+            if (nl == 0) leafId[0] = ~m; else if (nl == 1) leafId[1] = ~m; else if (nl == 2) leafId[2] = ~m; else *errorFlag = 1u;
+            nl++; cnt += min(A.leafSize, A.nitems - (uint32_t)(~m) * A.leafSize);
+        };
+        if (ref < 0) add(ref);
+        else {
+            const int2 c = A.children[ref];
+            int2 cx = make_int2(0, 0), cy = make_int2(0, 0);
+            if (c.x >= 0) cx = A.children[c.x];
+            if (c.y >= 0) cy = A.children[c.y];
+            if (c.x < 0) add(c.x); else { add(cx.x); add(cx.y); }
+            if (c.y < 0) add(c.y); else { add(cy.x); add(cy.y); }
+        }
+        if (nl > kMaxLeafTris) nl = kMaxLeafTris;
+        if (cnt > kMaxLeafTris) { *errorFlag = 1u; cnt = kMaxLeafTris; }
+    }
+    // what the group needs to know about every slot, in two words: internal (8 bits) | items (8 x 2 bits) | occupied (8 bits), and the lane that holds each slot
+    const uint32_t bySlot = group_or((internalChild ? 1u << mySlot : 0u) | (cnt << (8u + 2u * mySlot)) | (occupied ? 1u << (24u + mySlot) : 0u));
+    const uint32_t laneOfSlot = group_or(sub << (4u * mySlot));
+    const uint32_t imask = bySlot & 0xFFu, itemFields = (bySlot >> 8) & 0xFFFFu;
+    const uint32_t nInternal = __popc(imask), nItems = __popc(itemFields & 0x5555u) + 2u * __popc(itemFields & 0xAAAAu);
+    const uint32_t ci = __popc(imask & ((1u << mySlot) - 1u));
+    const uint32_t before = itemFields & ((1u << (2u * mySlot)) - 1u), ti = __popc(before & 0x5555u) + 2u * __popc(before & 0xAAAAu);
+    uint32_t childBase = 0, itemBase = 0;
+    if (active && sub == 0) {
+        if (nInternal) childBase = atomicAdd(nodesCtr, nInternal);
+        if (nItems) itemBase = atomicAdd(itemsCtr, nItems);
+    }
+    childBase = __shfl(childBase, 0, 8); itemBase = __shfl(itemBase, 0, 8);
+
+    // 5. what each slot leaves behind
+    uint32_t meta = 0;
+    if (internalChild) {
+        if (active) { if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = ref; else *errorFlag = 1u; }
+        meta = 0x20u | (24u + mySlot);
+    } else if (occupied) {
+        if (ti + cnt > 24u) *errorFlag = 1u;
+        uint32_t run = 0;
+        #pragma unroll
+        for (uint32_t k = 0; k < kMaxLeafTris; k++) {
+            if (k >= nl) break;
+            const uint32_t l = (uint32_t)leafId[k];
+            if (active) A.leafDst[l] = itemBase + ti + run;
+            run += min(A.leafSize, A.nitems - l * A.leafSize);
+        }
+        meta = ((((1u << cnt) - 1u) << 5) | ti) & 0xFFu;
+    }
+    if (active) A.slotRefs[(size_t)w * 8 + mySlot] = occupied ? ref : kEmptyRef;
+
+    // 6. origin, per-axis power-of-two scale and this slot's 8-bit box (quantise_node's arithmetic, the eight slots side by side)
+    const float p[3] = { nlo.x, nlo.y, nlo.z }, ph[3] = { nhi.x, nhi.y, nhi.z };
+    const float cl3[3] = { lo.x, lo.y, lo.z }, ch3[3] = { hi.x, hi.y, hi.z };
+    const bool valid = p[0] <= ph[0] && p[1] <= ph[1] && p[2] <= ph[2] && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])
+                       && isfinite(ph[0]) && isfinite(ph[1]) && isfinite(ph[2]);
+    uint32_t qlo[3], qhi[3], eb[3];
     #pragma unroll
-    for (int s = 0; s < 8; s++) { const uint32_t c = (childAtPacked >> (4 * s)) & 0xFu; childAt[s] = c == 0xFu ? -1 : (int)c; }
-    // children and items of this node, in slot order. A leaf child is a leaf of the binary tree or a whole subtree of at most
-    // kMaxLeafTris items: its (at most three) binary leaves are found by walking it -- they need not be neighbours in the sorted order
-    uint32_t nInternal = 0, nItems = 0, imask = 0, cntItem[8], nLeaf[8]; int leafIds[8][kMaxLeafTris];
-    for (int s = 0; s < 8; s++) {
-        const int c = childAt[s];
-        if (c < 0) continue;
-        if (!leafChild[c]) { nInternal++; imask |= 1u << s; continue; }
-        int st[2 * kMaxLeafTris]; int sp = 0; uint32_t nl = 0, cnt = 0;
-        st[sp++] = refs[c];
-        while (sp > 0) {
-            const int m = st[--sp];
-            if (m < 0) {
-                if (nl < kMaxLeafTris) leafIds[c][nl] = ~m; else *errorFlag = 1u;
-                nl++; cnt += min(A.leafSize, A.nitems - (uint32_t)(~m) * A.leafSize);
-            } else if (sp + 2 <= (int)(2 * kMaxLeafTris)) { const int2 cm = A.children[m]; st[sp++] = cm.y; st[sp++] = cm.x; }
-            else *errorFlag = 1u;
-        }
-        nLeaf[c] = min(nl, kMaxLeafTris); cntItem[c] = cnt;
-        nItems += cnt;
-    }
-    const uint32_t childBase = nInternal ? atomicAdd(nodesCtr, nInternal) : 0u;
-    const uint32_t itemBase = nItems ? atomicAdd(itemsCtr, nItems) : 0u;
-    WideNode node; memset(&node, 0, sizeof node);
-    node.childBase = childBase; node.triBase = itemBase; node.expImask = imask << 24;
-    float4 slo[8], shi[8]; int srefs[8];
-    uint32_t ci = 0, ti = 0; uint8_t meta[8];
-    for (int s = 0; s < 8; s++) {
-        const int c = childAt[s];
-        meta[s] = 0; srefs[s] = kEmptyRef; slo[s] = make_float4(0, 0, 0, 0); shi[s] = slo[s];
-        if (c >= 0) {
-            srefs[s] = refs[c]; slo[s] = lo[c]; shi[s] = hi[c];
-            if (!leafChild[c]) {
-                if (childBase + ci < A.nodeCapacity) A.binaryRootOf[childBase + ci] = refs[c]; else *errorFlag = 1u;
-                ci++;
-                meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
-            } else {
-                const uint32_t cnt = cntItem[c];
-                if (cnt > kMaxLeafTris || ti + cnt > 24u) *errorFlag = 1u;
-                uint32_t run = 0;
-                for (uint32_t k = 0; k < nLeaf[c]; k++) {
-                    const uint32_t l = (uint32_t)leafIds[c][k];
-                    A.leafDst[l] = itemBase + ti + run;
-                    run += min(A.leafSize, A.nitems - l * A.leafSize);
+    for (int a = 0; a < 3; a++) {
+        const float ext = valid ? ph[a] - p[a] : 0.0f;
+        int e;
+        (void)frexpf(ext * (1.0f / 255.0f), &e);
+        if (!(ext > 0.0f)) e = -126;
+        const bool boxed = valid && occupied && cl3[a] <= ch3[a];
+        bool done = false;
+        uint32_t ql = 255u, qh = 0u;
+        for (int tries = 0; tries < 256; tries++) {
+            if (!__builtin_amdgcn_ballot_w64(!done)) break;
+            if (!done) {
+                if (e < -126) e = -126;
+                const float scale = ldexpf(1.0f, e), inv = ldexpf(1.0f, -e);
+                bool ok = true;
+                if (boxed) {
+                    float fl = floorf((cl3[a] - p[a]) * inv), fh = ceilf((ch3[a] - p[a]) * inv);
+                    fl = fminf(fmaxf(fl, 0.0f), 255.0f); fh = fmaxf(fh, 0.0f);
+                    while (fl > 0.0f && p[a] + fl * scale > cl3[a]) fl -= 1.0f;
+                    while (fh <= 255.0f && p[a] + fh * scale < ch3[a]) fh += 1.0f;
+                    ok = !(fh > 255.0f);
+                    ql = (uint32_t)fl; qh = (uint32_t)fminf(fh, 255.0f);
                 }
-                meta[s] = (uint8_t)((((1u << cnt) - 1u) << 5) | ti);
-                ti += cnt;
+                const bool groupOk = group_ballot(!ok) == 0u;     // (lanes of a group are done together: the vote is among lanes in this branch)
+                if (groupOk || e >= 127) done = true; else e++;
             }
         }
-        A.slotRefs[(size_t)w * 8 + s] = srefs[s];
+        qlo[a] = ql; qhi[a] = qh; eb[a] = (uint32_t)(e + 127);
     }
-    node.meta[0] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
-    node.meta[1] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
-    quantise_node(node, nlo, nhi, slo, shi, srefs);
-    A.nodes[w] = node;
+    // 7. the node: every lane collects the eight slots' bytes, lane 0 of the group stores
+    const uint32_t mine0 = qlo[0] | (qlo[1] << 8) | (qlo[2] << 16) | (meta << 24), mine1 = qhi[0] | (qhi[1] << 8) | (qhi[2] << 16);
+    uint32_t s0[8], s1[8];
+    #pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int src = (int)((laneOfSlot >> (4 * s)) & 0xFu);
+        s0[s] = __shfl(mine0, src, 8); s1[s] = __shfl(mine1, src, 8);
+    }
+    if (active && sub == 0) {
+        auto bytes = [](const uint32_t* v, int first, int shift) -> uint32_t {
+            return ((v[first] >> shift) & 0xFFu) | (((v[first + 1] >> shift) & 0xFFu) << 8) | (((v[first + 2] >> shift) & 0xFFu) << 16) | (((v[first + 3] >> shift) & 0xFFu) << 24);
+        };
+        WideNode node;
+        node.origin[0] = valid ? p[0] : 0.0f; node.origin[1] = valid ? p[1] : 0.0f; node.origin[2] = valid ? p[2] : 0.0f;
+        node.expImask = (imask << 24) | eb[0] | (eb[1] << 8) | (eb[2] << 16);
+        node.childBase = childBase; node.triBase = itemBase;
+        node.meta[0] = bytes(s0, 0, 24); node.meta[1] = bytes(s0, 4, 24);
+        node.qlox[0] = bytes(s0, 0, 0);  node.qlox[1] = bytes(s0, 4, 0);
+        node.qloy[0] = bytes(s0, 0, 8);  node.qloy[1] = bytes(s0, 4, 8);
+        node.qloz[0] = bytes(s0, 0, 16); node.qloz[1] = bytes(s0, 4, 16);
+        node.qhix[0] = bytes(s1, 0, 0);  node.qhix[1] = bytes(s1, 4, 0);
+        node.qhiy[0] = bytes(s1, 0, 8);  node.qhiy[1] = bytes(s1, 4, 8);
+        node.qhiz[0] = bytes(s1, 0, 16); node.qhiz[1] = bytes(s1, 4, 16);
+        A.nodes[w] = node;
+    }
 }
 
 // Small trees (top levels of a few thousand instances, small meshes): ONE workgroup walks the wide tree level by level (a node's
@@ -664,7 +766,10 @@ __global__ __launch_bounds__(1024) void k_collapse(CollapseArgs A)
     for (; level < kMaxWideLevels; level++) {
         const uint32_t begin = sBegin, end = sEnd;
         if (begin >= end) break;
-        for (uint32_t w = begin + tid; w < end; w += blockDim.x) collapse_node(A, w, &sNodes, &sItems, &sError);
+        for (uint32_t base = begin; base < end; base += blockDim.x / 8u) {              // uniform bounds: collapse_node is a wave-wide call
+            const uint32_t w = base + tid / 8u;
+            collapse_node(A, w, w < end, &sNodes, &sItems, &sError);
+        }
         __syncthreads();
         if (tid == 0) { sBegin = end; sEnd = min(sNodes, A.nodeCapacity); }
         __syncthreads();
@@ -691,7 +796,10 @@ __global__ __launch_bounds__(64) void k_collapse_level(CollapseArgs A, CollapseS
 {
     const uint32_t begin = st->begin, end = st->end;               // stable for the whole launch: only its last workgroup rewrites them
     if (begin >= end) return;
-    for (uint32_t w = begin + blockIdx.x * blockDim.x + threadIdx.x; w < end; w += gridDim.x * blockDim.x) collapse_node(A, w, &st->nodes, &st->items, &st->error);
+    for (uint32_t base = begin + blockIdx.x * (blockDim.x / 8u); base < end; base += gridDim.x * (blockDim.x / 8u)) {
+        const uint32_t w = base + threadIdx.x / 8u;
+        collapse_node(A, w, w < end, &st->nodes, &st->items, &st->error);
+    }
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&st->ticket, 1u) == gridDim.x - 1u) {     // every workgroup has published its nodes
@@ -736,12 +844,6 @@ __global__ void k_scatter_tris(const TriPacket* __restrict__ src, const uint32_t
     dst[slot] = src[prim];
     dstIdx[slot] = srcIdx[prim];
     if (slotOfPrim) slotOfPrim[prim] = slot;
-}
-
-__global__ void k_scatter_order(const uint32_t* __restrict__ indexSorted, const uint32_t* __restrict__ leafDst, uint32_t n, uint32_t* __restrict__ order)
-{
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < n) order[leafDst[l]] = indexSorted[l];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -908,7 +1010,7 @@ hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipSt
     return hipGetLastError();
 }
 
-// TLAS over n instances: nodes into out.nodes, instance order list into out.order. build_tlas_prepare sizes the arrays (grow-only:
+// TLAS over n instances: nodes into out.nodes (the order of the leaf items is tree.indexSorted through tree.leafDst). build_tlas_prepare sizes the arrays (grow-only:
 // a rebuild with no more instances than before allocates nothing); build_tlas_device only enqueues kernels -- no sync, no
 // allocation; the header (node count, depth) stays on the device until the caller reads it.
 hipError_t build_tlas_prepare(Tlas& out, uint32_t n)
@@ -917,12 +1019,10 @@ hipError_t build_tlas_prepare(Tlas& out, uint32_t n)
     BVH_CHECK(ensure_tree_buffers(out.tree, n, 1, false));
     if (n > out.capacity || !out.nodes) {
         if (out.nodes) hipFree(out.nodes);
-        if (out.order) hipFree(out.order);
         if (out.rootBounds) hipFree(out.rootBounds);
-        out.nodes = nullptr; out.order = nullptr; out.rootBounds = nullptr; out.capacity = 0;
+        out.nodes = nullptr; out.rootBounds = nullptr; out.capacity = 0;
         const uint32_t cap = n ? n : 1;
         BVH_CHECK(hipMalloc((void**)&out.nodes, sizeof(WideNode) * wide_node_capacity(cap)));
-        BVH_CHECK(hipMalloc((void**)&out.order, sizeof(uint32_t) * ((cap + 3) / 4 * 4)));
         BVH_CHECK(hipMalloc((void**)&out.rootBounds, sizeof(float) * 8));
         out.capacity = cap;
     }
@@ -934,12 +1034,10 @@ hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* cons
 {
     hipError_t err = hipSuccess;
     out.instanceCount = n;
-    if (n) {
-        k_init_bounds<<<1, 64, 0, stream>>>(out.tree.bounds);
+    if (n) {                                                 // (launch_instance_records has reset out.tree.bounds)
         k_instance_boxes<<<std::min(cdiv(n, 4), 256u), 256, 0, stream>>>(dInstances, dBlasBounds, n, out.tree.boxLo, out.tree.boxHi, out.tree.bounds);
     }
     BVH_CHECK(build_wide_tree(out.tree, n, 1, 1, kCostInstance, kTlasCubicCells, true, out.nodes, out.rootBounds, stream));
-    if (n) k_scatter_order<<<cdiv(n, 256), 256, 0, stream>>>(out.tree.indexSorted, out.tree.leafDst, n, out.order);
     BVH_CHECK(hipGetLastError());
 fail:
     return err;
@@ -969,9 +1067,10 @@ __host__ __device__ void invert_3x4(const float m[12], float out[12])
 // D3D12_RAYTRACING_INSTANCE_DESC (as uploaded by BuildTopLevelAccelerationStructure, RaytracingHelpers.ixx:60-63) -> instance
 // records; the bottom-level table maps the id the host resolved to the arrays of that BLAS
 __global__ void k_instance_records(const InstanceSource* __restrict__ src, const BlasEntry* __restrict__ table, uint32_t n,
-                                   InstanceRecord* __restrict__ rec, const float** __restrict__ bounds)
+                                   InstanceRecord* __restrict__ rec, const float** __restrict__ bounds, uint32_t* sceneBounds)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6u) sceneBounds[i] = i < 3u ? 0xFFFFFFFFu : 0u;          // what k_init_bounds writes: k_instance_boxes, the next launch, accumulates into them
     if (i >= n) return;
     const InstanceSource s = src[i];
     const BlasEntry b = table[s.blasSlot];
@@ -983,74 +1082,62 @@ __global__ void k_instance_records(const InstanceSource* __restrict__ src, const
     bounds[i] = b.rootBounds;
 }
 
-__global__ void k_blob_instances(const InstanceRecord* __restrict__ inst, const float4* __restrict__ itemLo, const float4* __restrict__ itemHi,
-                                 const BlasEntry* __restrict__ table, uint32_t n, InstanceT* __restrict__ out)
+// What the traversal copy holds, in ONE launch (five until round 3; a dynamic frame pays ~5 us per launch): the first instBlocks workgroups
+// take one instance each thread, in Morton order l -- instance i = indexSorted[l], TLAS leaf position p = leafDst[l] -- and write its record
+// three times: API order (shading looks instances up by index), leaf order (the TLAS's "triangles"), and the entry record of the
+// streaming traversal: what entering an instance needs in one fetch -- worldToObject (3 units), node base | triangle base | triangle
+// count (24 bits) + mask | InstanceIndex (1 unit), and a copy of the BLAS's root node (5 units, read from the BLAS itself), so that the step that
+// enters the instance also visits its root. The remaining workgroups run the copy jobs: BLAS nodes / packets / vertex indices and the
+// TLAS's nodes into their sections (device to device, 16 B per lane, 64 workgroups per job).
+__global__ __launch_bounds__(256) void k_blob_assemble(const InstanceRecord* __restrict__ inst, const float4* __restrict__ itemLo, const float4* __restrict__ itemHi,
+                                                       const BlasEntry* __restrict__ table, uint32_t n, const uint32_t* __restrict__ indexSorted,
+                                                       const uint32_t* __restrict__ leafDst, InstanceT* __restrict__ outInst, InstanceT* __restrict__ outLeaf,
+                                                       uint4* __restrict__ outEnter, const BlobCopy* __restrict__ jobs, uint32_t njobs, uint32_t instBlocks)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (blockIdx.x >= instBlocks) {
+        const uint32_t cb = blockIdx.x - instBlocks, lanesOfJob = 64u * 256u;
+        for (uint32_t j = cb / 64u; j < njobs; j += (gridDim.x - instBlocks) / 64u) {
+            const BlobCopy c = jobs[j];
+            const uint4* s = (const uint4*)c.src; uint4* d = (uint4*)c.dst;
+            for (uint64_t i = (uint64_t)(cb % 64u) * 256u + threadIdx.x; i < c.n16; i += lanesOfJob) d[i] = s[i];
+        }
+        return;
+    }
+    const uint32_t l = blockIdx.x * 256u + threadIdx.x;
+    if (l >= n) return;
+    const uint32_t i = indexSorted[l], p = leafDst[l];
+    const InstanceRecord r = inst[i];
     InstanceT t;
-    for (int k = 0; k < 12; k++) t.worldToObject[k] = inst[i].worldToObject[k];
-    const float* M = inst[i].objectToWorld;
+    for (int k = 0; k < 12; k++) t.worldToObject[k] = r.worldToObject[k];
     float4 l4 = itemLo[i], h4 = itemHi[i];                                    // k_instance_boxes (the TLAS's items)
     pad_box(l4, h4);
-    const BlasEntry e = table[inst[i].blasSlot];
+    const BlasEntry e = table[r.blasSlot];
     t.boxLo[0] = l4.x; t.boxLo[1] = l4.y; t.boxLo[2] = l4.z; t.nodeBase = e.nodeBase;
     t.boxHi[0] = h4.x; t.boxHi[1] = h4.y; t.boxHi[2] = h4.z; t.triBase = e.triBase;
-    t.mask = inst[i].mask; t.triCount = inst[i].triCount; t.instanceID = inst[i].instanceID; t.instanceIndex = i;
-    for (int k = 0; k < 12; k++) t.objectToWorld[k] = M[k];
-    out[i] = t;
+    t.mask = r.mask; t.triCount = r.triCount; t.instanceID = r.instanceID; t.instanceIndex = i;
+    for (int k = 0; k < 12; k++) t.objectToWorld[k] = r.objectToWorld[k];
+    outInst[i] = t;
+    outLeaf[p] = t;
+    const uint4* tv = (const uint4*)&t; const uint4* root = (const uint4*)r.nodes;
+    uint4* en = outEnter + (size_t)p * kInst16;
+    en[0] = tv[0]; en[1] = tv[1]; en[2] = tv[2];
+    en[3] = make_uint4(t.nodeBase, t.triBase, (t.triCount < 0xFFFFFFu ? t.triCount : 0xFFFFFFu) | (t.mask << 24), t.instanceIndex);
+    for (uint32_t k = 0; k < kNode16; k++) en[4 + k] = root[k];
 }
 
-// the same records once more in the order of the TLAS leaves: the TLAS's "triangles"
-__global__ void k_blob_leaf_instances(const InstanceT* __restrict__ api, const uint32_t* __restrict__ order, uint32_t n, InstanceT* __restrict__ leaf)
+hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, uint32_t* sceneBounds, hipStream_t stream)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                 // one 16-byte unit per thread
-    if (t >= n * kInst16) return;
-    const uint32_t p = t / kInst16, part = t - p * kInst16;
-    ((uint4*)leaf)[t] = ((const uint4*)api)[order[p] * kInst16 + part];
-}
-
-// one block per copy job: BLAS nodes / packets and the TLAS pieces into their blob sections (device-to-device, 16 B per lane)
-__global__ __launch_bounds__(256) void k_blob_copy(const BlobCopy* __restrict__ jobs, uint32_t njobs)
-{
-    for (uint32_t j = blockIdx.y; j < njobs; j += gridDim.y) {
-        const BlobCopy c = jobs[j];
-        const uint4* s = (const uint4*)c.src; uint4* d = (uint4*)c.dst;
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c.n16; i += (uint64_t)gridDim.x * blockDim.x) d[i] = s[i];
-    }
-}
-
-hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, hipStream_t stream)
-{
-    if (n) k_instance_records<<<cdiv(n, 256), 256, 0, stream>>>(src, table, n, rec, bounds);
+    if (n) k_instance_records<<<cdiv(n, 256), 256, 0, stream>>>(src, table, n, rec, bounds, sceneBounds);
     return hipGetLastError();
 }
 
-// Entry records of the streaming traversal, in TLAS leaf order: what entering an instance needs, in one fetch -- worldToObject (3
-// units), node base | triangle base | triangle count (24 bits) + mask | InstanceIndex (1 unit), and a copy of the BLAS's root node
-// (5 units), so that the step that enters the instance also visits its root. Runs after k_blob_copy (reads the blob's node section).
-__global__ void k_blob_enter_records(const InstanceT* __restrict__ api, const uint32_t* __restrict__ order, uint32_t n,
-                                     const uint4* __restrict__ blobNodes, uint4* __restrict__ out)
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const Tlas& tlas, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+                                InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs, f4v* outEnter, hipStream_t stream)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;                 // one 16-byte unit per thread
-    if (t >= n * kInst16) return;
-    const uint32_t p = t / kInst16, part = t - p * kInst16;
-    const InstanceT* src = &api[order[p]];
-    uint4 v;
-    if (part < 3u) v = ((const uint4*)src)[part];
-    else if (part == 3u) v = make_uint4(src->nodeBase, src->triBase, (src->triCount < 0xFFFFFFu ? src->triCount : 0xFFFFFFu) | (src->mask << 24), src->instanceIndex);
-    else v = blobNodes[(size_t)src->nodeBase * kNode16 + (part - 4u)];
-    out[t] = v;
-}
-
-hipError_t launch_blob_assembly(const InstanceRecord* inst, const float4* itemLo, const float4* itemHi, const BlasEntry* table, uint32_t n, InstanceT* outInst,
-                                const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs,
-                                const f4v* blobNodes, f4v* outEnter, hipStream_t stream)
-{
-    if (n) k_blob_instances<<<cdiv(n, 256), 256, 0, stream>>>(inst, itemLo, itemHi, table, n, outInst);
-    if (n) k_blob_leaf_instances<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, outLeafInst);
-    if (njobs) k_blob_copy<<<dim3(64, njobs < 1024 ? njobs : 1024), 256, 0, stream>>>(jobs, njobs);
-    if (n) k_blob_enter_records<<<cdiv(n * kInst16, 256), 256, 0, stream>>>(outInst, order, n, (const uint4*)blobNodes, (uint4*)outEnter);
+    const uint32_t instBlocks = cdiv(n, 256), copyBlocks = 64u * (njobs < 1024u ? njobs : 1024u);
+    if (instBlocks + copyBlocks)
+        k_blob_assemble<<<instBlocks + copyBlocks, 256, 0, stream>>>(inst, tlas.tree.boxLo, tlas.tree.boxHi, table, n, tlas.tree.indexSorted, tlas.tree.leafDst,
+                                                                     outInst, outLeafInst, (uint4*)outEnter, jobs, njobs, instBlocks);
     return hipGetLastError();
 }
 

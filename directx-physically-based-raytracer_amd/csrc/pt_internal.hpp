@@ -46,7 +46,6 @@ struct Blas {
 
 struct Tlas {
     WideNode* nodes = nullptr;               // capacity wide_node_capacity(capacity)
-    uint32_t* order = nullptr;               // instance index of each TLAS leaf item (the blob holds the instance records in this order)
     float* rootBounds = nullptr;
     InstanceRecord* instances = nullptr;     // device, indexed by InstanceIndex
     const float** blasBounds = nullptr;      // device, per instance: root bounds of its BLAS
@@ -169,10 +168,9 @@ hipError_t build_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, bool 
 hipError_t refit_blas_device(const PtGeometryDesc* geoms, uint32_t ngeoms, hipStream_t stream, Blas& b);
 hipError_t build_tlas_prepare(Tlas& out, uint32_t n);
 hipError_t build_tlas_device(const InstanceRecord* dInstances, const float* const* dBlasBounds, uint32_t n, hipStream_t stream, Tlas& out);
-hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, hipStream_t stream);
-hipError_t launch_blob_assembly(const InstanceRecord* inst, const float4* itemLo, const float4* itemHi, const BlasEntry* table, uint32_t n, InstanceT* outInst,
-                                const uint32_t* order, InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs,
-                                const f4v* blobNodes, f4v* outEnter, hipStream_t stream);
+hipError_t launch_instance_records(const InstanceSource* src, const BlasEntry* table, uint32_t n, InstanceRecord* rec, const float** bounds, uint32_t* sceneBounds, hipStream_t stream);
+hipError_t launch_blob_assembly(const InstanceRecord* inst, const Tlas& tlas, const BlasEntry* table, uint32_t n, InstanceT* outInst,
+                                InstanceT* outLeafInst, const BlobCopy* jobs, uint32_t njobs, f4v* outEnter, hipStream_t stream);
 __host__ __device__ void invert_3x4(const float m[12], float out[12]);
 
 // pt_skin.hip
