@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, P
 // (v_writelane / v_readlane on the VALU pipe the kernel is bound by). Behind a pointer each field is an s_load where it is used.
 struct RoundArgs {
     SceneView sv; FrameView fv; PtTextures tx; BlobView bv; PathQueue qin, qout;
-    const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap, _pad;
+    const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap;
+    uint32_t objectsInLds;                   // objects whose resolved geometry + material are staged behind the blob (0: none)
     const uint4* primary;
 };
 
@@ -351,12 +352,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (bq * 256u < nT) {                                        // block-uniform
         PT_LDS_AS void* ldsStack = (PT_LDS_AS void*)smem;
         BlobReader<LDS> blob;
+        ObjectTableLds objLds = nullptr;
         if constexpr (LDS) {
             f4v* dst = (f4v*)(smem + kFixed);
             const uint32_t n16 = bv.bytes / 16u;
             for (uint32_t k = threadIdx.x; k < n16; k += 256u) dst[k] = bv.base[k];
+            const uint32_t nobj = A->objectsInLds;                // behind the blob: the object table (pt_shade.hpp ObjectTableLds)
+            for (uint32_t k = threadIdx.x; k < nobj * kObjLds16; k += 256u) {
+                const uint32_t o = k / kObjLds16, part = k - o * kObjLds16;
+                dst[n16 + k] = part < 2u ? ((const f4v*)&sv.shadeGeom[o])[part] : ((const f4v*)&sv.objects[o].Material)[part - 2u];
+            }
             __syncthreads();
             blob.p = (const PT_LDS_AS f4v*)(smem + kFixed);
+            if (nobj) objLds = (ObjectTableLds)(smem + kFixed) + n16;
         } else {
             blob.p = bv.base;
         }
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             bool toTraced = false, toFresh = false;
             v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
             if (valid) {
-                shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
+                shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv, objLds }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
                                        V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD, prof);
             }
             PT_PROF_MARK(prof, 6);
@@ -628,6 +636,16 @@ static void timing_begin(Context& c, std::vector<hipEvent_t>& ev, uint32_t k)
 }
 static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if (c.timing) hipEventRecord(ev[2 * k + 1], c.stream); }
 
+// Objects whose resolved geometry + material k_round stages in LDS behind the blob: all of them, if that does not cost the kernel its fourth
+// workgroup per CU (160 KB / 4, the kernel's static words and the 512-byte allocation granule counted); otherwise none.
+static uint32_t round_objects_in_lds(const Context& c, const SceneView& sv)
+{
+    if (c.blob.bytes > kBlobLdsMax || !sv.objectCount || !sv.shadeGeom) return 0u;
+    const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
+    const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + sv.objectCount * kObjLds16 * 16u + 128u;
+    return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? sv.objectCount : 0u;
+}
+
 // the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
@@ -639,7 +657,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
     {
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
-        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
+        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u) + round_objects_in_lds(c, sv) * kObjLds16 * 16u;
         // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
         const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
         if (!lds && !(c.debugFlags & lockStep)) {
@@ -759,7 +777,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
             std::memset(&a, 0, sizeof a);
             a.sv = sv; a.fv = fv; a.tx = tx; a.bv = c.blob; a.qin = c.queue[r & 1]; a.qout = c.queue[(r + 1) & 1];
             a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * kCountStride]; a.countOut = &c.queueCounts[(r + 1) * kCountStride];
-            a.counters = c.counters; a.segCap = segCap; a.primary = c.primaryRecords;
+            a.counters = c.counters; a.segCap = segCap; a.primary = c.primaryRecords; a.objectsInLds = round_objects_in_lds(c, sv);
         }
         if ((e = hipMemcpyAsync(c.roundArgs, host.data(), sizeof(RoundArgs) * (rounds + 1), hipMemcpyHostToDevice, c.stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(c.stream)) != hipSuccess) return e;    // once per change of the scene / frame geometry, never per frame

@@ -110,8 +110,15 @@ PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView
     return g;
 }
 
+// Object table of a small scene staged in LDS by the fused round kernel (kObjLds16 units of 16 B per object: ShadeGeom | Material): the
+// two records every hit looks up by object index -- the resolved geometry, which the normal fetch depends on, and the material -- then
+// cost an LDS read instead of a round trip to L2. nullptr: read them where the caller keeps them.
+constexpr uint32_t kObjLds16 = (sizeof(ShadeGeom) + sizeof(PtMaterial)) / 16u;
+static_assert(sizeof(ShadeGeom) == 32 && sizeof(PtMaterial) == 64 && offsetof(PtObjectData, Material) % 16 == 0, "layout");
+typedef const PT_LDS_AS f4v* ObjectTableLds;
+
 template <bool TEXTURED>
-PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t inst, float bu, float bv, v3 rayDir, SurfaceHit& h)
+PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t inst, float bu, float bv, v3 rayDir, SurfaceHit& h, ObjectTableLds objLds = nullptr)
 {
     const TriPacket& tp = hg.tp;
     const uint32_t geom = __float_as_uint(tp.a.w), prim = __float_as_uint(tp.b.w);
@@ -124,7 +131,11 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
     // Vertex attributes: the object's resolved geometry (ONE fetch: buffer pointers, stride, offsets -- instead of object record ->
     // descriptor table) and the triangle's vertex indices, which came with the hit geometry (no index-buffer fetch): two dependent
     // loads from hit to normals where the reference's chain (RaytracingHelpers.hlsli:82-105) has four.
-    const ShadeGeom sg = sv.shadeGeom[h.ObjectIndex];
+    ShadeGeom sg;
+    if (objLds) {
+        const f4v a = objLds[h.ObjectIndex * kObjLds16], b = objLds[h.ObjectIndex * kObjLds16 + 1u];
+        f4v* d = (f4v*)&sg; d[0] = a; d[1] = b;
+    } else sg = sv.shadeGeom[h.ObjectIndex];
     const uint32_t nOff = sg.nOff;
     if (nOff != ~0u) {                                     // HitInfo.hlsli:52-65
         v3 nrm[3];
@@ -162,9 +173,15 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
 PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
 
 template <bool TEXTURED>
-PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h)
+PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h, ObjectTableLds objLds = nullptr)
 {
-    if (!TEXTURED) return sv.objects[h.ObjectIndex].Material;           // EvaluateMaterial with every Descriptor == ~0u
+    if (!TEXTURED) {                                                     // EvaluateMaterial with every Descriptor == ~0u
+        if (!objLds) return sv.objects[h.ObjectIndex].Material;
+        PtMaterial m; f4v* d = (f4v*)&m;
+        #pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) d[k] = objLds[h.ObjectIndex * kObjLds16 + 2u + k];
+        return m;
+    }
     return evaluate_material(h.ShadingNormal, h.IsFrontFace ? h.Tangent : -h.Tangent, &sv.objects[h.ObjectIndex], sv.heap, sv.srgbLut,
                              h.TextureCoordinates);                       // ShadingHelpers.hlsli:161-235
 }
@@ -306,7 +323,7 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const
 // ---- the bodies of k_shade, shared with the fused round kernel k_round ----------------------------------------
 // A traced path at its hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304. hit = (instance, triangle slot, u, v).
 template <bool LDS> struct GeometryFromBlob {                // ... out of the scene blob (LDS-resident when LDS)
-    const BlobReader<LDS>& blob; const BlobView& bv;
+    const BlobReader<LDS>& blob; const BlobView& bv; ObjectTableLds objects = nullptr;
     PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry<LDS>(blob, bv, inst, slot); }
 };
 
@@ -320,9 +337,9 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
         p.srad = madd(p.thr, environment_light_color(sv, sd, rayDir), p.srad);
     } else {                                                 // :293-304
         SurfaceHit h;
-        reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h);
+        reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h, geometry.objects);
         PT_PROF_MARK(prof, 5);
-        const PtMaterial m = surface_material<TEXTURED>(sv, h);
+        const PtMaterial m = surface_material<TEXTURED>(sv, h, geometry.objects);
         BSDFSample bs;
         bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
         goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD, lobe);
