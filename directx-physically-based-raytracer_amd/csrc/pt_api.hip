@@ -77,6 +77,7 @@ void pt_destroy(PtContext* ctx)
     for (Context* v : c.viewers) {
         hipStreamSynchronize(v->stream);
         v->sceneOwner = nullptr; v->tlas = Tlas(); v->blobDev = nullptr; v->blobCapacity = 0; v->blob = BlobView{}; v->haveTlas = false;
+        v->blasTableDev = nullptr; v->instSourceDev = nullptr; v->blasTableCount = 0; v->normalsShared = false;
         v->objects = nullptr; v->objectCount = 0; v->instanceData = nullptr; v->instanceDataCount = 0;
         if (v->graphExec) { hipGraphExecDestroy(v->graphExec); v->graphExec = nullptr; v->graphKey.clear(); }
     }
@@ -94,6 +95,8 @@ void pt_destroy(PtContext* ctx)
     if (c.tlasHeaderEvent) hipEventDestroy(c.tlasHeaderEvent);
     if (c.validateDev) hipFree(c.validateDev);
     if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
+    if (c.shadeRecA) hipFree(c.shadeRecA);
+    if (c.shadeRecB) hipFree(c.shadeRecB);
     for (int k = 0; k < 2; k++) {
         PathQueue& q = c.queue[k];
         void* ptrs[6] = { q.s0, q.s1, q.s2, q.r0, q.r1, q.hit };
@@ -209,7 +212,7 @@ static int check_geometries(Context& c, const PtGeometryDesc* geometries, uint32
     return PT_OK;
 }
 
-static void drop_tlas(Context& c) { c.haveTlas = false; c.tlasBlasIds.clear(); }
+static void drop_tlas(Context& c) { c.haveTlas = false; c.tlasBlasIds.clear(); c.blasTableDev = nullptr; c.instSourceDev = nullptr; c.blasTableCount = 0; c.normalsShared = false; }
 
 // the traversal stack holds at most two entries per level of both trees (a node group and, in the streaming form, a postponed
 // leaf group) plus the three of an instance transition (pt_trace.hpp)
@@ -345,7 +348,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     std::map<uint64_t, uint32_t> pieceOf;
     std::vector<BlasEntry> table;
     uint32_t blobNodes = tlasNodeCap, blobTris = 0;
-    uint64_t tris = 0, objectEnd = 0;
+    uint64_t tris = 0, objectEnd = 0, bindingHash = 1469598103934665603ull;
     const size_t srcBytes = sizeof(InstanceSource) * (size_t)count;
     // staged in pinned host memory, two buffers taken in turn, each guarded by an event recorded behind the copy that read it: the host
     // may be a build ahead of the stream (a dynamic frame never synchronises) without rewriting bytes a copy has yet to read
@@ -357,7 +360,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         const Blas& b = it->second;
         auto pb = pieceOf.find(descs[i].AccelerationStructure);
         if (pb == pieceOf.end()) {
-            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris, b.idx });
+            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris, b.idx, descs[i].InstanceID & 0xFFFFFFu, b.geometryCount });
             blobNodes += b.nodeCount; blobTris += b.triCount;
             pieceIds.push_back(descs[i].AccelerationStructure);
             pb = pieceOf.emplace(descs[i].AccelerationStructure, (uint32_t)table.size() - 1).first;
@@ -368,6 +371,7 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         memcpy(up.data() + sizeof(InstanceSource) * (size_t)i, &src, sizeof src);
         tris += b.triCount;
         objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
+        bindingHash = (bindingHash ^ src.instanceID) * 1099511628211ull; bindingHash = (bindingHash ^ descs[i].AccelerationStructure) * 1099511628211ull;
     }
     const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
     const size_t idxBytes = (size_t)blobTris * 16;
@@ -438,6 +442,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     }
     const InstanceSource* dSrc = (const InstanceSource*)c.tlasUploadDev;
     const BlasEntry* dTable = (const BlasEntry*)((const uint8_t*)c.tlasUploadDev + tableOff);
+    c.blasTableDev = dTable; c.blasTableCount = (uint32_t)table.size(); c.instSourceDev = dSrc; c.blasTableMaxTris = 0;
+    for (const BlasEntry& te : table) c.blasTableMaxTris = std::max(c.blasTableMaxTris, te.triCount);
     const BlobCopy* dJobs = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + jobsOff);
 
     // ---- device side, all in stream order
@@ -457,8 +463,8 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;
-    if (objectEnd != c.tlasObjectEnd || count != c.tlasValidatedCount) c.validated = false;     // same instances over the same objects: nothing new to check
-    c.tlasObjectEnd = objectEnd; c.tlasValidatedCount = count;
+    if (objectEnd != c.tlasObjectEnd || count != c.tlasValidatedCount || bindingHash != c.tlasBindingHash) c.validated = false;     // same instances of the same bottom levels over the same objects: nothing new to check
+    c.tlasObjectEnd = objectEnd; c.tlasValidatedCount = count; c.tlasBindingHash = bindingHash;
     c.haveTlas = true;
     return PT_OK;
 }
@@ -482,6 +488,7 @@ int pt_share_scene(PtContext* ctx, PtContext* source)
     c.tlas = Tlas();
     c.tlas.instances = s.tlas.instances; c.tlas.instanceCount = s.tlas.instanceCount; c.tlas.triangleCount = s.tlas.triangleCount;   // views
     c.blob = s.blob;
+    c.blasTableDev = s.blasTableDev; c.blasTableCount = s.blasTableCount; c.blasTableMaxTris = s.blasTableMaxTris; c.instSourceDev = s.instSourceDev; c.normalsShared = false;
     c.tlasObjectEnd = s.tlasObjectEnd; c.maxBlasDepth = s.maxBlasDepth;
     c.heapHost = s.heapHost; c.heapDirty = true;                            // the descriptor table is copied (each context uploads its own)
     c.objects = s.objects; c.objectCount = s.objectCount; c.instanceData = s.instanceData; c.instanceDataCount = s.instanceDataCount;
@@ -588,8 +595,9 @@ static int validate_scene(Context& c)
                     + "] but only " + std::to_string(c.objectCount) + " objects are bound (pt_set_object_data)");
     if (c.instanceData && c.instanceDataCount < c.tlas.instanceCount)
         return fail(&c, PT_ERROR_INVALID_ARGUMENT, "InstanceData holds fewer records than the top level has instances");
+    uint32_t sharedMismatch = 0;
     if (c.objectCount) {
-        if (!c.validateDev) API_HIP(&c, hipMalloc((void**)&c.validateDev, sizeof(uint32_t) * 4));
+        if (!c.validateDev) API_HIP(&c, hipMalloc((void**)&c.validateDev, sizeof(uint32_t) * 8));
         if (c.objectCount > c.shadeGeomCap) {                // the resolved-geometry table the same kernel fills (grow-only; kernels in flight may read the old one)
             API_HIP(&c, hipStreamSynchronize(c.stream));
             if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
@@ -597,11 +605,15 @@ static int validate_scene(Context& c)
             API_HIP(&c, hipMalloc((void**)&c.shadeGeomDev, sizeof(ShadeGeom) * c.objectCount));
             c.shadeGeomCap = c.objectCount;
         }
-        API_HIP(&c, hipMemsetAsync(c.validateDev, 0, sizeof(uint32_t) * 4, c.stream));
+        API_HIP(&c, hipMemsetAsync(c.validateDev, 0, sizeof(uint32_t) * 8, c.stream));
         API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev, c.shadeGeomDev));
-        uint32_t r[4] = { 0, 0, 0, 0 };
+        // do all instances of a bottom level name the same vertex data? (the frame's normal records are made from the first one's objects)
+        if (c.blasTableDev && c.instSourceDev)
+            API_HIP(&c, launch_check_shared_geometry(c.stream, c.instSourceDev, c.blasTableDev, c.blob.instCount, c.shadeGeomDev, c.validateDev));
+        uint32_t r[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         API_HIP(&c, hipMemcpyAsync(r, c.validateDev, sizeof r, hipMemcpyDeviceToHost, c.stream));
         API_HIP(&c, hipStreamSynchronize(c.stream));
+        sharedMismatch = r[4];
         if (r[0]) {
             static const char* what[] = { "", "MeshDescriptors.Vertices", "MeshDescriptors.Indices", "MeshDescriptors.MotionVectors", "TextureMapInfo.Descriptor" };
             return fail(&c, PT_ERROR_INVALID_ARGUMENT, std::string("ObjectData[") + std::to_string(r[1]) + "]." + what[r[0] < 5 ? r[0] : 0] + " = " + std::to_string(r[2])
@@ -609,6 +621,7 @@ static int validate_scene(Context& c)
         }
     }
     c.validated = true; c.validatedObjects = c.objects; c.validatedObjectCount = c.objectCount;
+    c.normalsShared = c.objectCount != 0 && c.blasTableDev != nullptr && sharedMismatch == 0;
     return PT_OK;
 }
 

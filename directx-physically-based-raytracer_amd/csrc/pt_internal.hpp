@@ -56,7 +56,8 @@ struct Tlas {
 
 // host -> device inputs of a top-level build, one upload per build
 struct InstanceSource { float transform[12]; uint32_t instanceID, mask, blasSlot, _pad; };
-struct BlasEntry { const WideNode* nodes; const TriPacket* tris; const float* rootBounds; uint32_t triCount, nodeCount, nodeBase, triBase; const uint4* idx; };
+struct BlasEntry { const WideNode* nodes; const TriPacket* tris; const float* rootBounds; uint32_t triCount, nodeCount, nodeBase, triBase; const uint4* idx;
+                   uint32_t objectBase, geometryCount; };   // InstanceID of the first instance that refers to the bottom level: ObjectData[objectBase + geometry] describes its meshes
 struct BlobCopy { const void* src; void* dst; uint64_t n16; };
 
 // What hit reconstruction needs of an object's geometry, resolved once per change of (ObjectData, heap) by the validation kernel: the
@@ -130,8 +131,14 @@ struct Context {
     uint32_t maxBlasDepth = 0, tlasInstanceCap = 0;
     size_t blobCapacity = 0;
     uint32_t tlasValidatedCount = ~0u, persistentGrid = 0;
+    uint64_t tlasBindingHash = 0;                     // over (InstanceID, bottom-level id) of the instances, in order: what the shared-geometry check depends on
     uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
     ShadeGeom* shadeGeomDev = nullptr; uint32_t shadeGeomCap = 0;
+    // per-frame copy of the vertex normals, one record per triangle packet of the traversal copy (pt_shade.hpp ShadeTables)
+    uint4* shadeRecA = nullptr; uint32_t* shadeRecB = nullptr; uint32_t shadeRecCap = 0;
+    const BlasEntry* blasTableDev = nullptr; uint32_t blasTableCount = 0; uint32_t blasTableMaxTris = 0;    // the top-level build's table of bottom levels (device; a viewer: the owner's)
+    const InstanceSource* instSourceDev = nullptr;
+    bool normalsShared = false;              // every instance of a bottom level resolves to the same vertex buffer / stride / normal offset (checked with the objects)
     bool validated = false; uint32_t* validateDev = nullptr;   // descriptor / index validation of the scene inputs (pt_api.hip make_views)
     const void* validatedObjects = nullptr; uint32_t validatedObjectCount = 0;
 
@@ -188,6 +195,8 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
 hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
 hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap);
+inline bool normal_records_usable(const Context& c) { return c.normalsShared && c.blasTableDev && c.shadeRecA && c.blob.triCount && c.blob.triCount <= c.shadeRecCap; }
+hipError_t launch_check_shared_geometry(hipStream_t stream, const InstanceSource* src, const BlasEntry* table, uint32_t n, const ShadeGeom* shadeGeom, uint32_t* out);
 hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);

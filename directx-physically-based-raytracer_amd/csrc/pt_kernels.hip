@@ -321,6 +321,8 @@ struct RoundArgs {
     SceneView sv; FrameView fv; PtTextures tx; BlobView bv; PathQueue qin, qout;
     const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap;
     uint32_t objectsInLds;                   // objects whose resolved geometry + material are staged behind the blob (0: none)
+    const uint4* recA; const uint32_t* recB; // the frame's normal records (null: none)
+    uint32_t recordsInLds, _pad;             // ... and how many of them are staged behind the object table (all or none)
     const uint4* primary;
 };
 
@@ -352,7 +354,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (bq * 256u < nT) {                                        // block-uniform
         PT_LDS_AS void* ldsStack = (PT_LDS_AS void*)smem;
         BlobReader<LDS> blob;
-        ObjectTableLds objLds = nullptr;
+        ShadeTables tables;
+        tables.recA = A->recA; tables.recB = A->recB;
         if constexpr (LDS) {
             f4v* dst = (f4v*)(smem + kFixed);
             const uint32_t n16 = bv.bytes / 16u;
@@ -362,9 +365,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const uint32_t o = k / kObjLds16, part = k - o * kObjLds16;
                 dst[n16 + k] = part < 2u ? ((const f4v*)&sv.shadeGeom[o])[part] : ((const f4v*)&sv.objects[o].Material)[part - 2u];
             }
+            const uint32_t nrec = A->recordsInLds, recBase = n16 + nobj * kObjLds16;       // then the normal records: A x nrec | B x nrec
+            for (uint32_t k = threadIdx.x; k < nrec; k += 256u) {
+                const uint4 a = A->recA[k];
+                dst[recBase + k] = (f4v){ __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w) };
+                ((uint32_t*)(dst + recBase + nrec))[k] = A->recB[k];
+            }
             __syncthreads();
             blob.p = (const PT_LDS_AS f4v*)(smem + kFixed);
-            if (nobj) objLds = (ObjectTableLds)(smem + kFixed) + n16;
+            if (nobj) tables.objects = (ObjectTableLds)(smem + kFixed) + n16;
+            if (nrec) { tables.recALds = (const PT_LDS_AS f4v*)(smem + kFixed) + recBase; tables.recBLds = (const PT_LDS_AS uint32_t*)((const PT_LDS_AS f4v*)(smem + kFixed) + recBase + nrec); }
         } else {
             blob.p = bv.base;
         }
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             bool toTraced = false, toFresh = false;
             v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
             if (valid) {
-                shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv, objLds }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
+                shade_traced<TEXTURED>(sv, GeometryFromBlob<LDS>{ blob, bv, tables }, sd, gs, tx, aux, p, make_uint4(h.inst, h.slot, __float_as_uint(h.u), __float_as_uint(h.v)), h.t,
                                        V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD, prof);
             }
             PT_PROF_MARK(prof, 6);
@@ -523,6 +533,50 @@ hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objec
     return hipGetLastError();
 }
 
+// The frame's normal records (pt_shade.hpp ShadeTables): one per triangle packet of the traversal copy, read from the vertex buffers the
+// objects name NOW. A bottom level is described by the objects of the first instance that refers to it (BlasEntry::objectBase);
+// k_check_shared_geometry, run with the validation, makes sure every other instance of it resolves to the same vertex data -- if one
+// does not, no records are kept and hits fetch their vertices themselves. grid.y: bottom levels of the top-level build's table.
+__global__ __launch_bounds__(256) void k_capture_normals(const BlasEntry* __restrict__ table, const ShadeGeom* __restrict__ shadeGeom, uint4* __restrict__ recA, uint32_t* __restrict__ recB)
+{
+    const BlasEntry e = table[blockIdx.y];
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < e.triCount; k += gridDim.x * 256u) {
+        const uint32_t geom = __float_as_uint(e.tris[k].a.w);
+        const ShadeGeom sg = shadeGeom[e.objectBase + geom];
+        uint32_t n[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, has = 0;
+        if (sg.vb && sg.nOff != ~0u) {
+            const uint4 ix = e.idx[k];
+            const uint32_t vi[3] = { ix.x, ix.y, ix.z };
+            has = 1u;
+            #pragma unroll
+            for (int v = 0; v < 3; v++) {
+                const PT_GLOBAL_AS uint16_t* q = gptr<uint16_t>(sg.vb + (size_t)sg.stride * vi[v] + sg.nOff);
+                n[3 * v] = q[0]; n[3 * v + 1] = q[1]; n[3 * v + 2] = q[2];
+            }
+        }
+        recA[e.triBase + k] = make_uint4(n[0] | (n[1] << 16), n[2] | (n[3] << 16), n[4] | (n[5] << 16), n[6] | (n[7] << 16));
+        recB[e.triBase + k] = n[8] | (has << 16);
+    }
+}
+
+__global__ void k_check_shared_geometry(const InstanceSource* __restrict__ src, const BlasEntry* __restrict__ table, uint32_t n, const ShadeGeom* __restrict__ shadeGeom, uint32_t* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = src[i].instanceID, base = table[src[i].blasSlot].objectBase, ng = table[src[i].blasSlot].geometryCount;
+    if (id == base) return;
+    for (uint32_t g = 0; g < ng; g++) {
+        const ShadeGeom a = shadeGeom[id + g], b = shadeGeom[base + g];
+        if (a.vb != b.vb || a.stride != b.stride || a.nOff != b.nOff) { out[4] = 1u; return; }
+    }
+}
+
+hipError_t launch_check_shared_geometry(hipStream_t stream, const InstanceSource* src, const BlasEntry* table, uint32_t n, const ShadeGeom* shadeGeom, uint32_t* out)
+{
+    if (n) k_check_shared_geometry<<<(n + 255) / 256, 256, 0, stream>>>(src, table, n, shadeGeom, out);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_bsdf_evaluate(const float* __restrict__ q, uint32_t count, float* __restrict__ r)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -638,6 +692,7 @@ static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if
 
 // Objects whose resolved geometry + material k_round stages in LDS behind the blob: all of them, if that does not cost the kernel its fourth
 // workgroup per CU (160 KB / 4, the kernel's static words and the 512-byte allocation granule counted); otherwise none.
+static uint32_t lds_bytes_of_records(uint32_t n) { return (n * 20u + 15u) / 16u * 16u; }
 static uint32_t round_objects_in_lds(const Context& c, const SceneView& sv)
 {
     if (c.blob.bytes > kBlobLdsMax || !sv.objectCount || !sv.shadeGeom) return 0u;
@@ -645,19 +700,30 @@ static uint32_t round_objects_in_lds(const Context& c, const SceneView& sv)
     const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + sv.objectCount * kObjLds16 * 16u + 128u;
     return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? sv.objectCount : 0u;
 }
+// ... and the frame's normal records behind them, under the same rule
+static uint32_t round_records_in_lds(const Context& c, const SceneView& sv)
+{
+    const uint32_t nobj = round_objects_in_lds(c, sv);
+    if (!nobj || !normal_records_usable(c)) return 0u;
+    const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
+    const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + nobj * kObjLds16 * 16u + lds_bytes_of_records(c.blob.triCount) + 128u;
+    return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? c.blob.triCount : 0u;
+}
 
 // the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
     const uint32_t cstride = kCountStride;                                     // traced + fresh counters + the streaming form's cursor, per round
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
+    if (normal_records_usable(c))                          // the frame's normal records, from the vertex buffers as they are now
+        k_capture_normals<<<dim3(std::min((c.blasTableMaxTris + 255u) / 256u, 64u), c.blasTableCount), 256, 0, c.stream>>>(c.blasTableDev, sv.shadeGeom, c.shadeRecA, c.shadeRecB);
     k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues], c.primaryRecords);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     {
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
-        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u) + round_objects_in_lds(c, sv) * kObjLds16 * 16u;
+        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u) + round_objects_in_lds(c, sv) * kObjLds16 * 16u + lds_bytes_of_records(round_records_in_lds(c, sv));
         // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
         const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
         if (!lds && !(c.debugFlags & lockStep)) {
@@ -735,6 +801,16 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     const PtGraphicsSettings& gs = c.settings;
     const uint32_t npix = fv.width * fv.localRows;
     c.lastIterations = 0;
+    if (c.normalsShared && c.blasTableDev && c.blob.triCount > c.shadeRecCap) {       // the frame's normal records: 20 B per triangle packet (grow-only)
+        hipError_t ea = hipStreamSynchronize(c.stream);
+        if (ea != hipSuccess) return ea;
+        if (c.shadeRecA) hipFree(c.shadeRecA);
+        if (c.shadeRecB) hipFree(c.shadeRecB);
+        c.shadeRecA = nullptr; c.shadeRecB = nullptr; c.shadeRecCap = 0;
+        if ((ea = hipMalloc((void**)&c.shadeRecA, sizeof(uint4) * (size_t)c.blob.triCount)) != hipSuccess) return ea;
+        if ((ea = hipMalloc((void**)&c.shadeRecB, sizeof(uint32_t) * (size_t)c.blob.triCount)) != hipSuccess) return ea;
+        c.shadeRecCap = c.blob.triCount;
+    }
     if (npix == 0 || gs.SamplesPerPixel == 0) return hipSuccess;
     // a round = one k_shade + one k_extend. Per sample a path spends one round as "fresh" (bounce 0, no ray) and at
     // most Bounces rounds as "traced": spp * (Bounces + 1) rounds empty every queue.
@@ -763,6 +839,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
     key_add(key, c.frameConstants); key_add(key, c.primaryRecords); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
     key_add(key, c.framesInFlight);
+    key_add(key, c.shadeRecA); key_add(key, c.blasTableDev); key_add(key, c.blasTableCount); key_add(key, c.blasTableMaxTris); key_add(key, normal_records_usable(c));
     if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
         if (rounds + 1 > c.roundArgsCap) {
             if (c.roundArgs) hipFree(c.roundArgs);
@@ -778,6 +855,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
             a.sv = sv; a.fv = fv; a.tx = tx; a.bv = c.blob; a.qin = c.queue[r & 1]; a.qout = c.queue[(r + 1) & 1];
             a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * kCountStride]; a.countOut = &c.queueCounts[(r + 1) * kCountStride];
             a.counters = c.counters; a.segCap = segCap; a.primary = c.primaryRecords; a.objectsInLds = round_objects_in_lds(c, sv);
+            if (normal_records_usable(c)) { a.recA = c.shadeRecA; a.recB = c.shadeRecB; a.recordsInLds = round_records_in_lds(c, sv); }
         }
         if ((e = hipMemcpyAsync(c.roundArgs, host.data(), sizeof(RoundArgs) * (rounds + 1), hipMemcpyHostToDevice, c.stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(c.stream)) != hipSuccess) return e;    // once per change of the scene / frame geometry, never per frame

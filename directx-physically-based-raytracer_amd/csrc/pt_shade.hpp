@@ -88,7 +88,7 @@ PT_DEV uint32_t load_index_dev(const void* ib, uint32_t stride, uint32_t i)     
 // What hit reconstruction needs from the acceleration structure: the instance's two transforms, its InstanceID and the
 // triangle packet. Two sources with identical contents: the TLAS / BLAS arrays (k_gbuffer, k_shade) or the compact scene
 // blob, which the fused round kernel already holds in LDS for small scenes (two dependent HBM round trips less per hit).
-struct HitGeometry { float M[12], W[12]; uint32_t instanceID; TriPacket tp; uint32_t vi[3]; };      // vi: the triangle's vertex indices
+struct HitGeometry { float M[12], W[12]; uint32_t instanceID; TriPacket tp; uint32_t vi[3]; uint32_t triIndex; };      // vi: the triangle's vertex indices; triIndex: its packet in the traversal copy
 
 template <bool LDS>
 PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView& bv, uint32_t inst, uint32_t triSlot)
@@ -100,6 +100,7 @@ PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView
     const f4v pa = blob.ld(ta), pb = blob.ld(ta + 1), pc = blob.ld(ta + 2);
     const f4v ix = blob.ld(bv.idxOff16 + __float_as_uint(b1.w) + triSlot);
     HitGeometry g;
+    g.triIndex = __float_as_uint(b1.w) + triSlot;
     g.vi[0] = __float_as_uint(ix.x); g.vi[1] = __float_as_uint(ix.y); g.vi[2] = __float_as_uint(ix.z);
     g.tp.a = make_float4(pa.x, pa.y, pa.z, pa.w); g.tp.b = make_float4(pb.x, pb.y, pb.z, pb.w); g.tp.c = make_float4(pc.x, pc.y, pc.z, pc.w);
     g.instanceID = __float_as_uint(mk.z);
@@ -116,10 +117,20 @@ PT_DEV HitGeometry load_hit_geometry(const BlobReader<LDS>& blob, const BlobView
 constexpr uint32_t kObjLds16 = (sizeof(ShadeGeom) + sizeof(PtMaterial)) / 16u;
 static_assert(sizeof(ShadeGeom) == 32 && sizeof(PtMaterial) == 64 && offsetof(PtObjectData, Material) % 16 == 0, "layout");
 typedef const PT_LDS_AS f4v* ObjectTableLds;
+// Vertex normals per triangle packet, copied from the caller's vertex buffers at the START OF EVERY FRAME by k_capture_normals (so they are
+// as live as a fetch at hit time, frame by frame): the three normals of a hit are then one record fetch by packet index -- 20 bytes, A: nine
+// snorm16 minus the last, B: the last -- instead of resolved geometry -> three vertex fetches; for a small scene the fused round kernel keeps
+// the records in LDS, and no load of a traced tile's shading goes to memory at all. All null: fetch from the vertex buffers at the hit.
+struct ShadeTables {
+    ObjectTableLds objects = nullptr;
+    const PT_LDS_AS f4v* recALds = nullptr; const PT_LDS_AS uint32_t* recBLds = nullptr;
+    const uint4* recA = nullptr; const uint32_t* recB = nullptr;
+};
 
 template <bool TEXTURED>
-PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t inst, float bu, float bv, v3 rayDir, SurfaceHit& h, ObjectTableLds objLds = nullptr)
+PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t inst, float bu, float bv, v3 rayDir, SurfaceHit& h, const ShadeTables& tables = ShadeTables())
 {
+    const ObjectTableLds objLds = tables.objects;
     const TriPacket& tp = hg.tp;
     const uint32_t geom = __float_as_uint(tp.a.w), prim = __float_as_uint(tp.b.w);
     h.InstanceIndex = inst;
@@ -128,21 +139,36 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
     const float* M = hg.M; const float* W = hg.W;
     safe_triangle_spawn_point(V3(tp.a.x, tp.a.y, tp.a.z), V3(tp.b.x, tp.b.y, tp.b.z), V3(tp.c.x, tp.c.y, tp.c.z), bu, bv, M, W,
                               h.ObjectPosition, h.Position, h.FlatNormal, h.PositionOffset);
-    // Vertex attributes: the object's resolved geometry (ONE fetch: buffer pointers, stride, offsets -- instead of object record ->
-    // descriptor table) and the triangle's vertex indices, which came with the hit geometry (no index-buffer fetch): two dependent
-    // loads from hit to normals where the reference's chain (RaytracingHelpers.hlsli:82-105) has four.
-    ShadeGeom sg;
-    if (objLds) {
-        const f4v a = objLds[h.ObjectIndex * kObjLds16], b = objLds[h.ObjectIndex * kObjLds16 + 1u];
-        f4v* d = (f4v*)&sg; d[0] = a; d[1] = b;
-    } else sg = sv.shadeGeom[h.ObjectIndex];
+    // Vertex attributes. With the frame's normal records (ShadeTables) the three normals are ONE fetch by packet index; without them: the
+    // object's resolved geometry (one fetch: buffer pointers, stride, offsets -- instead of object record -> descriptor table) and the
+    // triangle's vertex indices, which came with the hit geometry (no index-buffer fetch), then the vertices -- two dependent loads from
+    // hit to normals where the reference's chain (RaytracingHelpers.hlsli:82-105) has four.
+    const bool records = tables.recALds != nullptr || tables.recA != nullptr;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+    if (records) {
+        if (tables.recALds) { const f4v a = tables.recALds[hg.triIndex]; w0 = __float_as_uint(a.x); w1 = __float_as_uint(a.y); w2 = __float_as_uint(a.z); w3 = __float_as_uint(a.w); w4 = tables.recBLds[hg.triIndex]; }
+        else { const uint4 a = tables.recA[hg.triIndex]; w0 = a.x; w1 = a.y; w2 = a.z; w3 = a.w; w4 = tables.recB[hg.triIndex]; }
+    }
+    ShadeGeom sg; sg.vb = nullptr; sg.ib = nullptr; sg.stride = 0; sg.ibStride = 0; sg.nOff = ~0u; sg.tOff = ~0u;
+    if (!records || TEXTURED) {
+        if (objLds) {
+            const f4v a = objLds[h.ObjectIndex * kObjLds16], b = objLds[h.ObjectIndex * kObjLds16 + 1u];
+            f4v* d = (f4v*)&sg; d[0] = a; d[1] = b;
+        } else sg = sv.shadeGeom[h.ObjectIndex];
+    }
     const uint32_t nOff = sg.nOff;
-    if (nOff != ~0u) {                                     // HitInfo.hlsli:52-65
+    if (records ? (w4 >> 16) != 0u : nOff != ~0u) {        // HitInfo.hlsli:52-65 (a record's upper half of B: the mesh has normals)
         v3 nrm[3];
-        #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const PT_GLOBAL_AS int16_t* q = gptr<int16_t>(sg.vb + (size_t)sg.stride * hg.vi[k] + nOff);
-            nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
+        if (records) {
+            nrm[0] = V3(unpack_r16_snorm((int16_t)(w0 & 0xFFFFu)), unpack_r16_snorm((int16_t)(w0 >> 16)), unpack_r16_snorm((int16_t)(w1 & 0xFFFFu)));
+            nrm[1] = V3(unpack_r16_snorm((int16_t)(w1 >> 16)), unpack_r16_snorm((int16_t)(w2 & 0xFFFFu)), unpack_r16_snorm((int16_t)(w2 >> 16)));
+            nrm[2] = V3(unpack_r16_snorm((int16_t)(w3 & 0xFFFFu)), unpack_r16_snorm((int16_t)(w3 >> 16)), unpack_r16_snorm((int16_t)(w4 & 0xFFFFu)));
+        } else {
+            #pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const PT_GLOBAL_AS int16_t* q = gptr<int16_t>(sg.vb + (size_t)sg.stride * hg.vi[k] + nOff);
+                nrm[k] = V3(unpack_r16_snorm(q[0]), unpack_r16_snorm(q[1]), unpack_r16_snorm(q[2]));
+            }
         }
         v3 n = interp3(nrm[0], nrm[1], nrm[2], bu, bv);          // Vertex::Interpolate, Vertex.hlsli:63-72
         v3 g = V3(sop3(W[0], n.x, W[4], n.y, W[8], n.z), sop3(W[1], n.x, W[5], n.y, W[9], n.z), sop3(W[2], n.x, W[6], n.y, W[10], n.z));
@@ -323,7 +349,7 @@ PT_DEV bool end_sample(const PtGraphicsSettings& gs, const PtTextures& tx, const
 // ---- the bodies of k_shade, shared with the fused round kernel k_round ----------------------------------------
 // A traced path at its hit (or miss) of bounce >= 1, Raytracing.hlsl:219-304. hit = (instance, triangle slot, u, v).
 template <bool LDS> struct GeometryFromBlob {                // ... out of the scene blob (LDS-resident when LDS)
-    const BlobReader<LDS>& blob; const BlobView& bv; ObjectTableLds objects = nullptr;
+    const BlobReader<LDS>& blob; const BlobView& bv; ShadeTables tables = ShadeTables();
     PT_DEV HitGeometry load(uint32_t inst, uint32_t slot) const { return load_hit_geometry<LDS>(blob, bv, inst, slot); }
 };
 
@@ -337,9 +363,9 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
         p.srad = madd(p.thr, environment_light_color(sv, sd, rayDir), p.srad);
     } else {                                                 // :293-304
         SurfaceHit h;
-        reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h, geometry.objects);
+        reconstruct_hit<TEXTURED>(sv, geometry.load(hr.x, hr.y), hr.x, __uint_as_float(hr.z), __uint_as_float(hr.w), rayDir, h, geometry.tables);
         PT_PROF_MARK(prof, 5);
-        const PtMaterial m = surface_material<TEXTURED>(sv, h, geometry.objects);
+        const PtMaterial m = surface_material<TEXTURED>(sv, h, geometry.tables.objects);
         BSDFSample bs;
         bs.Initialize(V3(m.BaseColor), m.Metallic, m.Roughness, m.IOR, m.Transmission, h.IsFrontFace);
         goes = scatter(gs, p, h, bs, material_emission(m), rayDir, newO, newD, lobe);

@@ -12,9 +12,10 @@ namespace pt {
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
-                                               const uint4* __restrict__ primary, BlobView bv)
+                                               const uint4* __restrict__ primary, BlobView bv, const uint4* __restrict__ recA, const uint32_t* __restrict__ recB)
 {
     BlobReader<false> blob; blob.p = bv.base;
+    ShadeTables tables; tables.recA = recA; tables.recB = recB;            // the frame's normal records (null: vertices are fetched at the hit)
     __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
     uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             p = load_path(qin, i);
             const uint4 hr = qin.hit[i];
             const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
-            shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
+            shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv, tables }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
         emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
@@ -262,8 +263,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 hipError_t launch_shade(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, const PathQueue& qin, const PathQueue& qout, float2* aux,
                         uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid)
 {
-    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob);
-    else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob);
+    const bool rec = normal_records_usable(c);
+    const uint4* recA = rec ? c.shadeRecA : nullptr; const uint32_t* recB = rec ? c.shadeRecB : nullptr;
+    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB);
+    else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB);
     return hipGetLastError();
 }
 

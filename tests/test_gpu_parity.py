@@ -193,6 +193,34 @@ def test_sky_instanced_and_large_mesh_within_tolerance(gpu, ptamd, oracle, pkg):
         assert st["rms"] < L2_TOLERANCE and st["max"] < SKY_ABS_TOLERANCE, st
 
 
+def test_instances_of_one_bottom_level_with_different_vertex_data(gpu, ptamd, oracle, pkg):
+    """The frame's normal records (csrc/pt_shade.hpp ShadeTables) describe a bottom level by the objects of its FIRST instance. ObjectData is
+    per (instance, geometry) in the reference (RaytracingHelpers.hlsli:79-85), so another instance of the same bottom level may name another
+    vertex buffer -- here: the same positions, other normals. The library has to notice (k_check_shared_geometry) and fetch the vertices of every
+    hit through that hit's own object, as the oracle does; with the second buffer dropped again the records come back. Bit-identical both times."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 160, 90
+    scene = S.instanced_grid(n=6, aspect=W / H)
+    mesh = scene.nodes[0].meshes[0]
+    other = mesh.vertices.copy()
+    other["Normal"] = other["Normal"][::-1].copy()              # other normals for the same positions
+    scene.heap.append(S.HeapItem(other, 0))
+    gs = S.graphics_settings(W, H, spp=2, bounces=4, ext_flags=0)
+    for swapped in (True, False):
+        for k in (3, 17, 30):                                    # three of the 36 instances of node 0 (one object each)
+            scene.object_data[int(scene.instance_ids[k])]["MeshDescriptors"]["Vertices"] = len(scene.heap) - 1 if swapped else scene.geometry[0][1]
+        out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+        ref_gb, ref_rays, ref_f32 = oracle.render(scene, gs, accel_mode=1, want_f32=True, layouts=L)
+        assert_gbuffer_identical(out, ref_gb)
+        assert c.PrimaryRays + c.SecondaryRays == ref_rays
+        st = ge.compare_radiance(out["RadianceF32"], ref_f32)
+        assert st["rms"] < L2_TOLERANCE and st["max"] < SKY_ABS_TOLERANCE, (swapped, st)
+        if swapped:
+            first = out["NormalRoughness"].copy()
+        else:
+            assert not np.array_equal(first, out["NormalRoughness"])      # the other normals were really used
+
+
 def test_lbvh_agrees_with_brute_force_on_incoherent_rays(gpu, ptamd, oracle, pkg):
     """LBVH traversal (conservative boxes, tie-break) vs the oracle's brute-force loop over every triangle."""
     S, L = pkg.scenes, pkg.layouts
