@@ -329,7 +329,10 @@ int  pt_gbuffer_render(PtContext* ctx, const PtGBufferConstants* constants, cons
 
 /* Raytracing::SetConstants + Raytracing::Render (Source/Raytracing.ixx:92-112): spp x (Bounces+1)
  * path-tracing loop per pixel, wavefront-scheduled; reads the G-buffer textures written by
- * pt_gbuffer_render for bounce 0 and stores the per-pixel radiance. */
+ * pt_gbuffer_render for bounce 0 and stores the per-pixel radiance.
+ * Vertex normals are read from the objects' vertex buffers once per call, at its start (in stream order), not at every hit:
+ * what a hit interpolates is what the buffers held when the call's work began. Tangents, texture coordinates and per-vertex
+ * motion are read at the hit. */
 int  pt_raytrace_set_constants(PtContext* ctx, const PtGraphicsSettings* settings);
 int  pt_raytrace_render(PtContext* ctx, const PtTextures* textures);
 
