@@ -215,6 +215,42 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConsta
     }
 }
 
+// k_pt_init and round 0 in ONE launch (the product paths): round 0 has fresh entries only, one per primary-hit pixel, in the order k_pt_init
+// wrote them -- so the block that gathers a tile of pixels into primary-surface records shades their first bounce right away, out of
+// the registers that hold the record, and emits the survivors as round 0 would have. The fresh state (48 B written, 48 B read), the record
+// read-back (48 B) and one launch per frame go away; values and draws are those of k_pt_init + shade_fresh.
+__global__ __launch_bounds__(256) void k_pt_first(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue qout, float2* aux,
+                                                                                             uint32_t segCap, uint32_t* countOut, uint4* __restrict__ primary)
+{
+    __shared__ uint32_t lds[32];
+    uint32_t emits = 0;
+    const PtCamera& cam = fc->cam; const PtGraphicsSettings& gs = fc->gs;
+    const uint32_t npix = fv.width * fv.localRows;
+    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t seg = sq * segCap;
+    for (uint32_t j = bq; (j * kSubQueues + sq) * 256u < npix; j += nbq) {
+        const uint32_t pix = (j * kSubQueues + sq) * 256u + threadIdx.x;
+        bool alive = false;
+        if (pix < npix) alive = isfinite(((const float*)tx.Position)[4 * (size_t)pix + 3]);
+        bool toTraced = false, toFresh = false;
+        PathRegs p; p.thr = V3(1.0f, 1.0f, 1.0f); p.srad = V3(0, 0, 0); p.rsum = V3(0, 0, 0); p.pixel = pix; p.rng = 0; p.sample = 0; p.bounce = 0;
+        v3 newO = V3(0, 0, 0), newD = V3(0, 0, 1);
+        if (alive) {
+            const uint32_t x = pix % fv.width, y = global_row(fv, pix / fv.width);
+            p.rng = rng_init(x, y, gs.FrameIndex);
+            if (aux) aux[pix] = make_float2(INFINITY, 1.0f);                             // hitDistance = inf, isDiffuse = true (:188-189)
+            const uint2 nr = ((const uint2*)tx.NormalRoughness)[pix], rad = ((const uint2*)tx.Radiance)[pix];
+            const uint4 r0 = ((const uint4*)tx.Position)[pix];
+            const uint4 r1 = make_uint4(nr.x, nr.y, ((const uint32_t*)tx.FlatNormal)[pix], ((const uint32_t*)tx.GeometricNormal)[pix]);
+            const uint4 r2 = make_uint4(((const uint32_t*)tx.BaseColorMetalness)[pix], rad.x, rad.y,
+                                        (uint32_t)((const uint16_t*)tx.IOR)[pix] | ((uint32_t)((const uint8_t*)tx.Transmission)[pix] << 16));
+            primary[3 * (size_t)pix] = r0; primary[3 * (size_t)pix + 1] = r1; primary[3 * (size_t)pix + 2] = r2;
+            shade_fresh_record(fv, cam, gs, tx, aux, r0, r1, r2, p, toTraced, toFresh, newO, newD);
+        }
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_extend_brute(AccelView av, BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
 {
     const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
@@ -717,7 +753,13 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
     if (normal_records_usable(c))                          // the frame's normal records, from the vertex buffers as they are now
         k_capture_normals<<<dim3(std::min((c.blasTableMaxTris + 255u) / 256u, 64u), c.blasTableCount), 256, 0, c.stream>>>(c.blasTableDev, sv.shadeGeom, c.shadeRecA, c.shadeRecB);
-    k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues], c.primaryRecords);
+    // the product paths start with k_pt_first (k_pt_init + round 0); the validation / statistics variants keep the two apart
+    const uint32_t lockStepFlags = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+    const uint32_t pairOnlyFlags = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+    const bool streamingForm = c.blob.bytes > kBlobLdsMax && !(c.debugFlags & lockStepFlags), fusedForm = !streamingForm && !(c.debugFlags & pairOnlyFlags);
+    const bool first = streamingForm || fusedForm;
+    if (first) k_pt_first<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[1], aux, segCap, &c.queueCounts[cstride], c.primaryRecords);
+    else k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues], c.primaryRecords);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     {
@@ -731,9 +773,11 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
             for (uint32_t r = 0; r <= rounds; r++) {
                 PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
                 uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
-                timing_begin(c, c.evShade, c.nShade);
-                launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, grid);
-                timing_end(c, c.evShade, c.nShade); c.nShade++;
+                if (r > 0) {                                                // (round 0's shading half ran inside k_pt_first)
+                    timing_begin(c, c.evShade, c.nShade);
+                    launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, grid);
+                    timing_end(c, c.evShade, c.nShade); c.nShade++;
+                }
                 if (r == rounds) break;
                 timing_begin(c, c.evExtend, c.nExtend);
                 // Fewer, longer-lived waves than the other kernels: a wave only keeps its lanes busy if it refills them many times, and with
@@ -748,7 +792,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         // fused rounds: everything except the validation / statistics variants, which keep the two-kernel form
         const uint32_t pairOnly = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
         if (!(c.debugFlags & pairOnly)) {
-            for (uint32_t r = 0; r <= rounds; r++) {                        // queues and counters of round r: in its argument block (launch_raytrace)
+            for (uint32_t r = 1; r <= rounds; r++) {                        // queues and counters of round r: in its argument block (launch_raytrace); round 0 ran inside k_pt_first
                 timing_begin(c, c.evRound, c.nRound);
                 #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(c.roundArgs + r)
                 #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)

@@ -375,16 +375,15 @@ PT_DEV void shade_traced(const SceneView& sv, const GEOMETRY& geometry, const Pt
 }
 
 // A fresh path: bounce 0 on the primary surface rebuilt from the G-buffer, Raytracing.hlsl:118-148,193-198
-PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux, const uint4* __restrict__ primary,
-                        PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD, RoundProf* prof = nullptr)
+// (r0, r1, r2: the pixel's primary-surface record)
+PT_DEV void shade_fresh_record(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux, uint4 r0, uint4 r1, uint4 r2,
+                               PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD)
 {
     const uint32_t pixel = p.pixel;
     const uint32_t px = pixel % fv.width, py = global_row(fv, pixel / fv.width);
     float uu, vv;
     const RayDesc primaryRay = generate_pinhole_ray(cam, px, py, fv.width, fv.height, uu, vv);   // :110-126
     const v3 rayDir = primaryRay.d;
-    const uint4 r0 = primary[3 * (size_t)pixel], r1 = primary[3 * (size_t)pixel + 1], r2 = primary[3 * (size_t)pixel + 2];
-    PT_PROF_WAIT(); PT_PROF_MARK(prof, 13);
     const float4 pos = make_float4(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z), __uint_as_float(r0.w));
     const short4 nr = make_short4((short)(r1.x & 0xFFFFu), (short)(r1.x >> 16), (short)(r1.y & 0xFFFFu), (short)(r1.y >> 16));
     const short2 fe = make_short2((short)(r1.z & 0xFFFFu), (short)(r1.z >> 16)), ge = make_short2((short)(r1.w & 0xFFFFu), (short)(r1.w >> 16));
@@ -408,6 +407,15 @@ PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphi
         toTraced = true;
         if (aux && first) aux[p.pixel].y = lobe == LOBE_DIFFUSE ? 1.0f : 0.0f;       // isDiffuse of the lobe sampled at bounce 0, :237
     } else toFresh = end_sample(gs, tx, aux, p);
+}
+
+PT_DEV void shade_fresh(const FrameView& fv, const PtCamera& cam, const PtGraphicsSettings& gs, const PtTextures& tx, float2* aux, const uint4* __restrict__ primary,
+                        PathRegs& p, bool& toTraced, bool& toFresh, v3& newO, v3& newD, RoundProf* prof = nullptr)
+{
+    const uint32_t pixel = p.pixel;
+    const uint4 r0 = primary[3 * (size_t)pixel], r1 = primary[3 * (size_t)pixel + 1], r2 = primary[3 * (size_t)pixel + 2];
+    PT_PROF_WAIT(); PT_PROF_MARK(prof, 13);
+    shade_fresh_record(fv, cam, gs, tx, aux, r0, r1, r2, p, toTraced, toFresh, newO, newD);
 }
 
 // compaction + stores of one tile: survivors to the traced region (state + ray), restarts to the fresh region (state).
