@@ -349,10 +349,10 @@ def main():
         kd = kernels[dom]
         # step level: every byte a frame has to move through HBM by construction of the data layout
         hit_pixels = W * H                                       # upper bound (camera inside the scene: every primary ray hits on C2)
-        frame_bytes = (W * H * 63.0 + hit_pixels * (47.0 + 48.0 + 48.0)     # G-buffer stores; k_pt_init: G-buffer read, fresh state + primary-surface record written
-                       + solo_secondary / args.steps * (268.0 + hbm_bvh)     # traced entries
-                       + hit_pixels * spp * (48.0 + 48.0 + 48.0 + 32.0)      # fresh entries: primary-surface record, state r + w, first ray written
-                       + W * H * 8.0)                                        # radiance out
+        frame_bytes = (W * H * 63.0 + hit_pixels * (47.0 + 48.0 + 48.0 + 32.0)          # G-buffer stores; k_pt_first: G-buffer read, primary-surface record written, the first sample's first bounce shaded in place: state + ray written
+                       + solo_secondary / args.steps * (268.0 + hbm_bvh)                 # traced entries
+                       + hit_pixels * (spp - 1) * (48.0 + 48.0 + 48.0 + 32.0)            # fresh entries of the later samples: primary-surface record, state r + w, first ray written
+                       + W * H * 8.0)                                                    # radiance out
         step_achieved = gbps(frame_bytes, latency_ms)
         traffic, traffic_note, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

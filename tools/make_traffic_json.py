@@ -33,8 +33,8 @@ for w in ("c2", "c3", "c5"):
     pm = parse(os.path.join(SRC, w + "_pmc_summary.txt"))
     ent = {"source_hash": bench.source_hash()}
     # the kernels of the product path of this workload (the statistics frame of bench.py runs other variants: not counted)
-    product = ("k_round<false", "k_gbuffer<false", "k_pt_init", "k_set_constants", "k_capture_normals") if w == "c2" else \
-              ("k_shade<false", "k_extend_stream<false", "k_gbuffer<false", "k_pt_init", "k_set_constants", "k_capture_normals")
+    product = ("k_round<false", "k_gbuffer<false", "k_pt_init", "k_pt_first", "k_set_constants", "k_capture_normals") if w == "c2" else \
+              ("k_shade<false", "k_extend_stream<false", "k_gbuffer<false", "k_pt_init", "k_pt_first", "k_set_constants", "k_capture_normals")
     frames = max(c["SQ_INSTS_VALU"][1] for k, c in pm.items() if "k_gbuffer<false" in k and "SQ_INSTS_VALU" in c)   # one G-buffer launch per frame
     valu_total = 0.0
     for k, c in pm.items():
