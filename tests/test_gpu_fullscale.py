@@ -163,3 +163,45 @@ def test_c4_cornell_4k_16spp_16_bounces(gpu, ptamd, oracle, pkg):
     # determinism at this size
     again, ca = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(3, 8, 16))
     assert np.array_equal(again["Radiance"], part["Radiance"]) and ca.SecondaryRays == cp.SecondaryRays
+
+
+def test_builder_across_mesh_sizes(gpu, ptamd, pkg):
+    """Every path of the on-device builder, by size: the one-leaf placeholder (1-2 triangles), two triangles per leaf (<= 32), one
+    workgroup collapsing the whole tree (<= 4096 leaves) and the per-level launches beyond, with a top level over as many instances
+    as there are meshes -- random triangle soups (overlapping boxes everywhere), some of them with duplicated and zero-area triangles.
+    Checked per size: the structural invariants of tests/bvh_check.py on the downloaded traversal copy, and the device's own
+    brute-force loop against the tree on every bounce ray of a small frame (PT_DEBUG_BRUTE_FORCE: BvhMismatches == 0)."""
+    S = pkg.scenes
+    rng = np.random.default_rng(2024)
+    W, H = 64, 48
+    sizes = [1, 2, 3, 4, 5, 8, 9, 31, 32, 33, 34, 63, 64, 65, 255, 256, 257, 1023, 4095, 4096, 4097, 4099, 9001]
+    meshes, objects = [], []
+    for k, n in enumerate(sizes):
+        c = rng.uniform(-1.0, 1.0, 3) * np.array([2.0, 1.0, 2.0]) + np.array([0.0, 0.0, 4.0])
+        v0 = c + 0.35 * rng.standard_normal((n, 3))
+        e1, e2 = 0.08 * rng.standard_normal((n, 3)), 0.08 * rng.standard_normal((n, 3))
+        pos = np.stack([v0, v0 + e1, v0 + e2], 1)
+        if n >= 8:
+            pos[1] = pos[0]                                         # an exact duplicate
+            pos[2, 2] = pos[2, 1]                                   # a zero-area triangle (two equal vertices)
+            pos[3, 1] = pos[3, 0]; pos[3, 2] = pos[3, 0]            # a point
+        mat = S.material(tuple(0.3 + 0.6 * rng.random(3)), metallic=float(k % 3 == 0), roughness=float(0.1 + 0.8 * rng.random()))
+        meshes.append(S.MeshNode([S.Mesh(S.make_vertices(pos.reshape(-1, 3)), S.make_indices(np.arange(3 * n)), False, mat)]))
+        objects.append(S.RenderObject(k, S.trs((0, 0, 0), 17.0 * k, (1.0, 1.0, 1.0))))
+    light = S.quad_mesh((-3, 0, -3), (3, 0, -3), (3, 0, 3), (-3, 0, 3), (0, -1, 0), S.material((0.8, 0.8, 0.8), emissive=(1, 1, 1), strength=8.0))
+    meshes.append(S.MeshNode([light])); objects.append(S.RenderObject(len(sizes), S.trs((0, 3.5, 4.0))))
+    cam = S.make_camera((0, 0.3, -1.5), hfov_deg=85.0, aspect=W / H)
+    scene = S.Scene(meshes, objects, cam, S.make_scene_data((0.5, 0.6, 0.8, 1.0)), name="sizes").finalize()
+    gpu.set_sharding(0, 1, 16)
+    g = ptamd.Scene(gpu, scene)
+    st, acc = check_structure(gpu, len(sizes) + 1, sum(sizes) + 2)
+    assert st["blas_depth"] <= 16
+    r = ptamd.Renderer(gpu, g, W, H)
+    gs = S.graphics_settings(W, H, spp=2, bounces=5, frame_index=3)
+    gpu.set_debug_flags(2); gpu.reset_counters()
+    r.render(gs); gpu.sync()
+    c = gpu.counters()
+    gpu.set_debug_flags(0)
+    g.close()
+    assert c.SecondaryRays > W * H and c.BvhMismatches == 0 and c.StackOverflows == 0
+
