@@ -195,7 +195,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
 hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
 hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap);
-inline bool normal_records_usable(const Context& c) { return c.normalsShared && c.blasTableDev && c.shadeRecA && c.blob.triCount && c.blob.triCount <= c.shadeRecCap; }
+inline bool normal_records_usable(const Context& c) { return c.normalsShared && c.blasTableDev && c.blasTableCount <= 65535u /* grid.y of k_capture_normals */ && c.shadeRecA && c.blob.triCount && c.blob.triCount <= c.shadeRecCap; }
 hipError_t launch_check_shared_geometry(hipStream_t stream, const InstanceSource* src, const BlasEntry* table, uint32_t n, const ShadeGeom* shadeGeom, uint32_t* out);
 hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
