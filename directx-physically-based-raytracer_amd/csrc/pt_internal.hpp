@@ -92,9 +92,12 @@ struct PathQueue {
     uint4*  hit;     // instance | triangle slot in the BLAS | u bits | v bits      (instance ~0u = miss)
 };
 
-// Queue geometry (pt_kernels.hip "wavefront path tracer"): the path queue is cut into kSubQueues independent sub-queues
-constexpr uint32_t kSubQueues = 32;
-constexpr uint32_t kCountStride = 3u * kSubQueues;      // per round: entries traced | fresh | cursor of the streaming form, one word per sub-queue
+// Queue geometry (pt_kernels.hip "wavefront path tracer"): the path queue is cut into independent sub-queues
+// How many: a power of two chosen per frame by the form that renders it (Context::sqShift = its log2). The fused round kernel likes 32 (C2: 64 -0.4 %,
+// 128 -0.9 %), the streaming form 128 (C5 +3 %, C3 +0.5 % over 32; 256 the same, 512 less): a sub-queue is then shared by 16 waves instead of 64,
+// cursors are less contended and run dry at a finer grain. Per round the counters are: entries traced | fresh | cursor of the streaming form,
+// one word per sub-queue each (3 << sqShift words).
+constexpr uint32_t kSubQueueShiftFused = 5, kSubQueueShiftStream = 7, kSubQueuesMax = 1u << kSubQueueShiftStream;
 
 struct FrameConstants { PtCamera cam; PtSceneData sd; PtGraphicsSettings gs; };
 struct RoundArgs;
@@ -133,6 +136,7 @@ struct Context {
     uint32_t tlasValidatedCount = ~0u, persistentGrid = 0;
     uint64_t tlasBindingHash = 0;                     // over (InstanceID, bottom-level id) of the instances, in order: what the shared-geometry check depends on
     uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
+    uint32_t sqShift = kSubQueueShiftFused;   // log2 of the number of sub-queues of the frame being enqueued (launch_raytrace)
     ShadeGeom* shadeGeomDev = nullptr; uint32_t shadeGeomCap = 0;
     // per-frame copy of the vertex normals, one record per triangle packet of the traversal copy (pt_shade.hpp ShadeTables)
     uint4* shadeRecA = nullptr; uint32_t* shadeRecB = nullptr; uint32_t shadeRecCap = 0;

@@ -189,14 +189,14 @@ __global__ void k_set_constants(FrameConstants v, FrameConstants* dst, uint32_t*
 // pixels in whatever order their paths ended, and eight scattered loads per lane, each using 1..16 bytes of its cache line, were the
 // most expensive part of a round (profiles/r03_round_prof_*.txt: 30 % of a wave's time in the fresh tiles).
 __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue q, float2* aux, uint32_t segCap, uint32_t* countFresh,
-                                                 uint4* __restrict__ primary)
+                                                 uint4* __restrict__ primary, uint32_t sqShift)
 {
     __shared__ uint32_t lds[8];
     const PtGraphicsSettings& gs = fc->gs;
     const uint32_t npix = fv.width * fv.localRows;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
-    for (uint32_t j = bq; (j * kSubQueues + sq) * 256u < npix; j += nbq) {
-        const uint32_t p = (j * kSubQueues + sq) * 256u + threadIdx.x;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
+    for (uint32_t j = bq; (j * nsq + sq) * 256u < npix; j += nbq) {
+        const uint32_t p = (j * nsq + sq) * 256u + threadIdx.x;
         bool alive = false;
         if (p < npix) alive = isfinite(((const float*)tx.Position)[4 * (size_t)p + 3]);
         const uint32_t slot = sq * segCap + (segCap - 1u - block_reserve(alive, &countFresh[sq], lds));
@@ -220,16 +220,16 @@ __global__ __launch_bounds__(256) void k_pt_init(FrameView fv, const FrameConsta
 // the registers that hold the record, and emits the survivors as round 0 would have. The fresh state (48 B written, 48 B read), the record
 // read-back (48 B) and one launch per frame go away; values and draws are those of k_pt_init + shade_fresh.
 __global__ __launch_bounds__(256) void k_pt_first(FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx, PathQueue qout, float2* aux,
-                                                                                             uint32_t segCap, uint32_t* countOut, uint4* __restrict__ primary)
+                                                                                             uint32_t segCap, uint32_t* countOut, uint4* __restrict__ primary, uint32_t sqShift)
 {
     __shared__ uint32_t lds[32];
     uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t npix = fv.width * fv.localRows;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
     const uint32_t seg = sq * segCap;
-    for (uint32_t j = bq; (j * kSubQueues + sq) * 256u < npix; j += nbq) {
-        const uint32_t pix = (j * kSubQueues + sq) * 256u + threadIdx.x;
+    for (uint32_t j = bq; (j * nsq + sq) * 256u < npix; j += nbq) {
+        const uint32_t pix = (j * nsq + sq) * 256u + threadIdx.x;
         bool alive = false;
         if (pix < npix) alive = isfinite(((const float*)tx.Position)[4 * (size_t)pix + 3]);
         bool toTraced = false, toFresh = false;
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256) void k_pt_first(FrameView fv, const FrameConst
             primary[3 * (size_t)pix] = r0; primary[3 * (size_t)pix + 1] = r1; primary[3 * (size_t)pix + 2] = r2;
             shade_fresh_record(fv, cam, gs, tx, aux, r0, r1, r2, p, toTraced, toFresh, newO, newD);
         }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[nsq + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
 }
 
-__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend_brute(AccelView av, BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters, uint32_t sqShift)
 {
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
@@ -288,11 +288,11 @@ constexpr uint32_t kExtendLdsFixed = kStackLds2Bytes + (uint32_t)kCandidates * 2
 constexpr uint32_t kBlobLdsMax = 40u * 1024u;
 
 template <bool STATS, bool LDS, bool WRITE_T = false, bool FLAT = false>
-__global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend2(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters, uint32_t sqShift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     if (bq * 256u >= n) return;                                   // block-uniform: nothing to do, skip the staging
@@ -358,7 +358,7 @@ struct RoundArgs {
     const FrameConstants* fc; float2* aux; const uint32_t* countIn; uint32_t* countOut; DeviceCounters* counters; uint32_t segCap;
     uint32_t objectsInLds;                   // objects whose resolved geometry + material are staged behind the blob (0: none)
     const uint4* recA; const uint32_t* recB; // the frame's normal records (null: none)
-    uint32_t recordsInLds, _pad;             // ... and how many of them are staged behind the object table (all or none)
+    uint32_t recordsInLds, sqShift;          // ... and how many of them are staged behind the object table (all or none); log2 of the number of sub-queues
     const uint4* primary;
 };
 
@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t emits = 0;
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
-    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
+    const uint32_t sqShift = A->sqShift;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
+    const uint32_t nT = countIn[sq], nF = countIn[nsq + sq];
     const uint32_t seg = sq * segCap;
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
 
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                        V3(d.x, d.y, d.z), toTraced, toFresh, newO, newD, prof);
             }
             PT_PROF_MARK(prof, 6);
-            emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+            emit_tile(qout, seg, segCap, &countOut[sq], &countOut[nsq + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
             PT_PROF_MARK(prof, 7);
 #ifdef PT_ROUND_PROF
             prof->acc[11] += 1u;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD, prof);
         }
         PT_PROF_MARK(prof, 14);
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[nsq + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
         PT_PROF_MARK(prof, 15);
     }
 #ifdef PT_ROUND_PROF
@@ -470,9 +471,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters)
+__global__ __launch_bounds__(256) void k_extend(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap, const uint32_t* count, DeviceCounters* counters, uint32_t sqShift)
 {
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
     const uint32_t n = count[sq];
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)n);
     __shared__ uint2 ldsStack[kLdsStackDepth * 256];
@@ -669,7 +670,7 @@ static uint32_t persistent_grid(Context& c)
     if (!c.persistentGrid) {                                        // asked once: hipGetDeviceProperties is a slow host call
         hipDeviceProp_t p;
         const uint32_t g = hipGetDeviceProperties(&p, c.device) == hipSuccess ? (uint32_t)p.multiProcessorCount * 8u : 1024u;   // 1536..4096 blocks perform alike on C2
-        c.persistentGrid = (g + kSubQueues - 1) / kSubQueues * kSubQueues;                                                        // whole number of blocks per sub-queue
+        c.persistentGrid = (g + kSubQueuesMax - 1) / kSubQueuesMax * kSubQueuesMax;                                                        // whole number of blocks per sub-queue
     }
     return c.persistentGrid;
 }
@@ -749,7 +750,7 @@ static uint32_t round_records_in_lds(const Context& c, const SceneView& sv)
 // the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
 {
-    const uint32_t cstride = kCountStride;                                     // traced + fresh counters + the streaming form's cursor, per round
+    const uint32_t nsq = 1u << c.sqShift, cstride = 3u * nsq;                  // traced + fresh counters + the streaming form's cursor, per round
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
     if (normal_records_usable(c))                          // the frame's normal records, from the vertex buffers as they are now
         k_capture_normals<<<dim3(std::min((c.blasTableMaxTris + 255u) / 256u, 64u), c.blasTableCount), 256, 0, c.stream>>>(c.blasTableDev, sv.shadeGeom, c.shadeRecA, c.shadeRecB);
@@ -758,8 +759,8 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
     const uint32_t pairOnlyFlags = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
     const bool streamingForm = c.blob.bytes > kBlobLdsMax && !(c.debugFlags & lockStepFlags), fusedForm = !streamingForm && !(c.debugFlags & pairOnlyFlags);
     const bool first = streamingForm || fusedForm;
-    if (first) k_pt_first<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[1], aux, segCap, &c.queueCounts[cstride], c.primaryRecords);
-    else k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[kSubQueues], c.primaryRecords);
+    if (first) k_pt_first<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[1], aux, segCap, &c.queueCounts[cstride], c.primaryRecords, c.sqShift);
+    else k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[nsq], c.primaryRecords, c.sqShift);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
     AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
     {
@@ -784,7 +785,7 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
                 // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
                 // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
                 // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-                launch_extend_stream(c, ac, qout, segCap, cout, cout + 2u * kSubQueues, grid, stats, wt);
+                launch_extend_stream(c, ac, qout, segCap, cout, cout + 2u * nsq, grid, stats, wt);
                 timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
             }
             return hipGetLastError();
@@ -817,13 +818,13 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         const bool lds = c.blob.bytes <= kBlobLdsMax;
         const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
         const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u);
-        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, c.blob, ac, qout, segCap, cout, c.counters);
+        if (c.debugFlags & PT_DEBUG_BRUTE_FORCE) k_extend_brute<<<grid, 256, 0, c.stream>>>(sv.accel, c.blob, ac, qout, segCap, cout, c.counters, c.sqShift);
         else if (c.debugFlags & PT_DEBUG_TRAVERSAL_V1) {
-            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
-            else k_extend<false><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters);
+            if (stats) k_extend<true><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters, c.sqShift);
+            else k_extend<false><<<grid, 256, 0, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters, c.sqShift);
         } else {
             const bool wt = aux != nullptr;                            // denoiser modes need CommittedRayT
-            #define PT_EXT2(S, L, W, F) k_extend2<S, L, W, F><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters)
+            #define PT_EXT2(S, L, W, F) k_extend2<S, L, W, F><<<grid, 256, smem, c.stream>>>(c.blob, ac, qout, segCap, cout, c.counters, c.sqShift)
             #define PT_EXT2_F(S, L, W) do { if (flat) PT_EXT2(S, L, W, true); else PT_EXT2(S, L, W, false); } while (0)
             #define PT_EXT2_W(S, L) do { if (wt) PT_EXT2_F(S, L, true); else PT_EXT2_F(S, L, false); } while (0)
             #define PT_EXT2_L(S) do { if (lds) PT_EXT2_W(S, true); else PT_EXT2_W(S, false); } while (0)
@@ -860,8 +861,10 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     // most Bounces rounds as "traced": spp * (Bounces + 1) rounds empty every queue.
     const uint32_t rounds = gs.SamplesPerPixel * (gs.Bounces + 1u);
     const uint32_t tiles = (npix + 255u) / 256u;
-    const uint32_t segCap = (tiles + kSubQueues - 1) / kSubQueues * 256u;     // entries per sub-queue segment
-    hipError_t e = ensure_queues(c, segCap * kSubQueues, (rounds + 2) * kCountStride);
+    c.sqShift = c.blob.bytes <= kBlobLdsMax ? kSubQueueShiftFused : kSubQueueShiftStream;          // (pt_internal.hpp: who likes how many sub-queues)
+    const uint32_t nsq = 1u << c.sqShift, cstride = 3u * nsq;
+    const uint32_t segCap = (tiles + nsq - 1) / nsq * 256u;                   // entries per sub-queue segment
+    hipError_t e = ensure_queues(c, segCap * nsq, (rounds + 2) * cstride);
     if (e != hipSuccess) return e;
     if (!c.frameConstants && (e = hipMalloc((void**)&c.frameConstants, sizeof(FrameConstants))) != hipSuccess) return e;
     if (gs.Denoiser != PT_DENOISER_NONE && npix > c.pixelAuxCapacity) {
@@ -871,10 +874,10 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
         c.pixelAuxCapacity = npix;
     }
     FrameConstants fc; fc.cam = c.camera; fc.sd = c.sceneData; fc.gs = c.settings;
-    k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * kCountStride);
+    k_set_constants<<<1, 256, 0, c.stream>>>(fc, c.frameConstants, c.queueCounts, (rounds + 2u) * cstride);
     // persistent grid, but never more blocks than the queue has tiles: surplus blocks only cost dispatch slots and LDS that
     // a concurrent frame's kernels (other streams) could use -- this matters for small shards (1/8 of a 1080p frame = 1013 tiles)
-    const uint32_t grid = std::min(persistent_grid(c), (tiles + kSubQueues - 1) / kSubQueues * kSubQueues);
+    const uint32_t grid = std::min(persistent_grid(c), (tiles + nsq - 1) / nsq * nsq);
     c.lastIterations = rounds + 1;
 
     // everything the launch sequence depends on: the key of the per-round argument blocks and of the captured graph
@@ -882,7 +885,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
     key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
     key_add(key, c.frameConstants); key_add(key, c.primaryRecords); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
-    key_add(key, c.framesInFlight);
+    key_add(key, c.framesInFlight); key_add(key, c.sqShift);
     key_add(key, c.shadeRecA); key_add(key, c.blasTableDev); key_add(key, c.blasTableCount); key_add(key, c.blasTableMaxTris); key_add(key, normal_records_usable(c));
     if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
         if (rounds + 1 > c.roundArgsCap) {
@@ -897,7 +900,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
             RoundArgs& a = host[r];
             std::memset(&a, 0, sizeof a);
             a.sv = sv; a.fv = fv; a.tx = tx; a.bv = c.blob; a.qin = c.queue[r & 1]; a.qout = c.queue[(r + 1) & 1];
-            a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * kCountStride]; a.countOut = &c.queueCounts[(r + 1) * kCountStride];
+            a.fc = c.frameConstants; a.aux = aux; a.countIn = &c.queueCounts[r * cstride]; a.countOut = &c.queueCounts[(r + 1) * cstride]; a.sqShift = c.sqShift;
             a.counters = c.counters; a.segCap = segCap; a.primary = c.primaryRecords; a.objectsInLds = round_objects_in_lds(c, sv);
             if (normal_records_usable(c)) { a.recA = c.shadeRecA; a.recB = c.shadeRecB; a.recordsInLds = round_records_in_lds(c, sv); }
         }

@@ -215,10 +215,10 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h, ObjectTab
 // ---------------------------------------------------------------------------------------------
 // wavefront path tracer
 // ---------------------------------------------------------------------------------------------
-// Queue geometry. The path queue is cut into kSubQueues independent sub-queues (segments of segCap entries,
+// Queue geometry. The path queue is cut into nsq = 1 << sqShift independent sub-queues (segments of segCap entries,
 // each with its own counter): a single returning atomic on one word saturates near 88 M/s on MI355X, which
 // at one atomic per wave made compaction the bottleneck of the whole frame. Pixel tile t (256 pixels) is
-// dealt to sub-queue t % kSubQueues, a path never leaves its sub-queue, so a segment can never overflow and
+// dealt to sub-queue t % nsq, a path never leaves its sub-queue, so a segment can never overflow and
 // every sub-queue samples the whole image (balanced). One atomic per 256-thread block and tile.
 
 // block-wide stream compaction: wave64 ballot + prefix popcount inside each wave, wave totals through LDS,

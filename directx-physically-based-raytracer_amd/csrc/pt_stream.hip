@@ -6,21 +6,21 @@
 
 namespace pt {
 
-// counts: [0..kSubQueues) traced, [kSubQueues..2*kSubQueues) fresh
+// counts: [0..nsq) traced, [nsq..2*nsq) fresh (nsq = 1 << sqShift sub-queues)
 // k_shade<false> wants 132 VGPRs, one more than four waves per SIMD allow; held to 128 it spills nothing and the fourth wave is worth
 // +1.8 % on C3 and +0.7 % on C5 (the kernel waits on its 268 B per ray, not on issue slots)
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
-                                               const uint4* __restrict__ primary, BlobView bv, const uint4* __restrict__ recA, const uint32_t* __restrict__ recB)
+                                               const uint4* __restrict__ primary, BlobView bv, const uint4* __restrict__ recA, const uint32_t* __restrict__ recB, uint32_t sqShift)
 {
     BlobReader<false> blob; blob.p = bv.base;
     ShadeTables tables; tables.recA = recA; tables.recB = recB;            // the frame's normal records (null: vertices are fetched at the hit)
     __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
     uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues, nbq = gridDim.x / kSubQueues;
-    const uint32_t nT = countIn[sq], nF = countIn[kSubQueues + sq];
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
+    const uint32_t nT = countIn[sq], nF = countIn[nsq + sq];
     const uint32_t seg = sq * segCap;
 
     for (uint32_t tile = bq; tile * 256u < nT; tile += nbq) {                // traced entries: hit records left by k_extend
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float4 rd = qin.r1[i];                                     // k_extend left t in r1.w (denoiser modes)
             shade_traced<TEXTURED>(sv, GeometryFromBlob<false>{ blob, bv, tables }, sd, gs, tx, aux, p, hr, rd.w, V3(rd.x, rd.y, rd.z), toTraced, toFresh, newO, newD);
         }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[nsq + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
     for (uint32_t tile = bq; tile * 256u < nF; tile += nbq) {                // fresh entries
         const uint32_t local = tile * 256u + threadIdx.x;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             p = load_path(qin, seg + (segCap - 1u - local));
             shade_fresh(fv, cam, gs, tx, aux, primary, p, toTraced, toFresh, newO, newD);
         }
-        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[kSubQueues + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
+        emit_tile(qout, seg, segCap, &countOut[sq], &countOut[nsq + sq], lds + ((emits++ & 1u) << 4), toTraced, toFresh, p, newO, newD);
     }
 }
 
@@ -73,10 +73,10 @@ constexpr bool kStreamTriPairs = true;                // two triangles of a leaf
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
 template <bool STATS, bool WRITE_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
-                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters)
+                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters, uint32_t sqShift)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t sq = blockIdx.x % kSubQueues, bq = blockIdx.x / kSubQueues;
+    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift;
     const uint32_t nT = count[sq];
     const uint32_t seg = sq * segCap;
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
@@ -265,8 +265,8 @@ hipError_t launch_shade(Context& c, const SceneView& sv, const FrameView& fv, co
 {
     const bool rec = normal_records_usable(c);
     const uint4* recA = rec ? c.shadeRecA : nullptr; const uint32_t* recB = rec ? c.shadeRecB : nullptr;
-    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB);
-    else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB);
+    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift);
+    else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift);
     return hipGetLastError();
 }
 
@@ -277,8 +277,8 @@ hipError_t launch_extend_stream(Context& c, const AlphaContext& ac, const PathQu
     // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
     // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
     // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-    const uint32_t sgrid = std::max(kSubQueues, std::min(grid, c.framesInFlight > 1 ? kStreamGridShared : kStreamGridAlone));
-    #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, q, segCap, count, cursor, c.counters)
+    const uint32_t sgrid = std::max(1u << c.sqShift, std::min(grid, c.framesInFlight > 1 ? kStreamGridShared : kStreamGridAlone));
+    #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, q, segCap, count, cursor, c.counters, c.sqShift)
     if (stats) { if (writeT) PT_XS(true, true); else PT_XS(true, false); } else { if (writeT) PT_XS(false, true); else PT_XS(false, false); }
     #undef PT_XS
     return hipGetLastError();
