@@ -11,8 +11,9 @@ total work is fixed as N grows => "scaling": "strong". Rays = primary (G-buffer)
 traced, counted on the device. One JSON line is printed by rank 0.
 
 Extra objects in the line (DESIGN.md "Measurement"):
-  roofline      algorithmic HBM bytes of a frame / one-frame latency vs 8 TB/s HBM, the dominant kernel on its own (per-launch HIP
-                events, single stream), the pipelined figure, BVH bytes by where they are served from, PMC traffic and VALU issue
+  roofline      the dominant kernel: algorithmic HBM bytes per launch (nothing that LDS serves) / its average launch duration (per-launch
+                HIP events on its stream, single stream) vs 8 TB/s, PMC traffic beside it; the whole frame alone and pipelined; BVH bytes by
+                where they are served from; VALU issue against the chip's best and against the ceiling at the kernels' occupancy
   cpu_baseline  the CPU oracle (oracle/, OpenMP) timed on this host on a bounded row slab of the same frame
 """
 import argparse
@@ -67,20 +68,53 @@ def make_scene(kind, aspect, S):
     raise ValueError(kind)
 
 
+def host_cpu_share():
+    """What this process may really use of the host: the affinity mask, the cgroup CPU quota, and what OpenMP will start."""
+    info = {"os_cpu_count": os.cpu_count() or 1, "sched_affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_max": None, "cgroup_cpus": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    info["cgroup_cpus"] = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0]); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                info["cgroup_cpu_max"] = f"{int(q)} {int(per)}"
+                if q > 0:
+                    info["cgroup_cpus"] = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
+
+
 def cpu_baseline(scene, gs, W, H, L, budget_s=15.0):
-    """Time the oracle (kind "port": the C restatement, OpenMP over scanlines, its own BVH) on a row slab."""
+    """Time the oracle (kind "port": the C restatement, OpenMP over scanlines, its own BVH) on a row slab: with as many threads as the
+    process may use (affinity mask and cgroup quota, not os.cpu_count()), and with ONE thread on a smaller slab."""
+    import ctypes
     oracle = ge.load_oracle()
     osc = oracle.OracleScene(scene, accel_mode=1)
     gb = {k: np.zeros((H, W, c), dt) for k, (dt, c) in L.GBUFFER_FORMATS.items()}
     consts = np.zeros((), L.GBUFFER_CONSTANTS)
     consts["RenderSize"] = (W, H); consts["Flags"] = L.GBufferFlags.DefaultNoDenoiser
-    cores = os.cpu_count() or 1
+    share = host_cpu_share()
+    usable = share["sched_affinity"]
+    if share["cgroup_cpus"]:
+        usable = max(1, min(usable, int(share["cgroup_cpus"] + 0.5)))
+    omp = None
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")                    # the copy the oracle is linked against
+        omp.omp_get_max_threads.restype = ctypes.c_int
+        share["omp_max_threads_default"] = int(omp.omp_get_max_threads())
+    except OSError:
+        share["omp_max_threads_default"] = None
 
-    def slab(rows):
+    def slab(rows, threads=usable):
         y0 = max(0, H // 2 - rows // 2); y1 = min(H, y0 + rows)
         t = time.perf_counter()
-        rays = osc.gbuffer(consts, gb, rows=(y0, y1))
-        rays += osc.raytrace(gs, gb, rows=(y0, y1))
+        rays = osc.gbuffer(consts, gb, rows=(y0, y1), threads=threads)
+        rays += osc.raytrace(gs, gb, rows=(y0, y1), threads=threads)
         return rays, time.perf_counter() - t, (y0, y1)
 
     rays, dt, _ = slab(8)                                   # calibration (also warms the threads up)
@@ -90,9 +124,16 @@ def cpu_baseline(scene, gs, W, H, L, budget_s=15.0):
     while dt < 0.66 * budget_s and reps < 64:               # fast hosts: repeat the slab until ~budget_s of CPU work
         r2, d2, _ = slab(rows)
         rays += r2; dt += d2; reps += 1
+    # the same oracle on ONE thread, ~3 s: what a core does, next to what the host does
+    r1, d1, _ = slab(2, 1)
+    rows1 = int(min(H, max(2, 2 * 3.0 / max(d1, 1e-4))))
+    r1, d1, (a0, a1) = slab(rows1, 1)
+    one = {"value": r1 / d1 / 1e6, "unit": "Mrays/s", "cores": 1, "sample": f"rows {a0}..{a1} ({r1} rays in {d1:.2f} s)"}
     osc.close()
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows {y0}..{y1} of the {W}x{H} frame x{reps} ({rays} rays in {dt:.2f} s), oracle/pt_oracle.c with its own BVH, OpenMP"}
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": int(usable), "kind": "port",
+            "sample": f"rows {y0}..{y1} of the {W}x{H} frame x{reps} ({rays} rays in {dt:.2f} s), oracle/pt_oracle.c with its own BVH, OpenMP",
+            "threads": int(usable), "one_thread": one, "host": share,
+            "parallel_efficiency": (rays / dt / 1e6) / (one["value"] * usable) if one else None}
 
 
 def self_launch(n):
@@ -139,7 +180,8 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="developer aid: a round as two launches (k_shade + k_extend2) instead of the fused k_round, to profile the halves separately")
     ap.add_argument("--rehearse-collective", action="store_true",
-                    help="developer aid for a 1-GPU box: run the N > 1 code path (process group, one RCCL communicator per lane, pt_gather_bands) with world size 1")
+                    help="developer aid for a 1-GPU box: run the N > 1 code path (process group, one RCCL communicator per lane, pt_gather_bands) with world size 1; "
+                         "the frame's 68 bands travel by grouped ncclSend / ncclRecv to the rank itself (PT_DEBUG_GATHER_SELF_EXCHANGE)")
     ap.add_argument("--launch-check", action="store_true",
                     help="developer aid / CPU test: stop after the process group is up (gloo, no GPU touched) and print the world size")
     args = ap.parse_args()
@@ -219,6 +261,8 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             lane.ctx.comm_init(uid[0], rank, world)
     BASE_FLAGS = 0x10 if args.unfused else 0                   # PT_DEBUG_UNFUSED_ROUNDS
+    if collective and world == 1:
+        BASE_FLAGS |= 0x80                                      # PT_DEBUG_GATHER_SELF_EXCHANGE: the rehearsal really issues ncclSend / ncclRecv (to itself), one pair per band
     for lane in lanes:
         lane.ctx.set_debug_flags(BASE_FLAGS)
     dyn_events = []
@@ -329,12 +373,18 @@ def main():
 
         all_rays = float(cs.PrimaryRays + cs.SecondaryRays)
         bvh_bytes_per_ray = (cs.NodesVisited * acc.NodeSizeBytes + cs.TrianglesTested * acc.TriangleSizeBytes) / all_rays
-        blob_in_lds = acc.BlobBytes <= 40 * 1024               # kBlobLdsMax: the traversal copy is staged into LDS by every block
-        # Algorithmic HBM bytes. Per secondary ray of the fused round: ray read 32 + path state 48 r + 48 w + ray
-        # write 32 + hit geometry 108 = 268 (the hit record stays in registers). Two-kernel form: traversal = ray read 32 + hit record
-        # write 16; shading = hit read 16 + ray direction 16 + state 96 + ray write 32 + geometry 108 = 268. BVH bytes count as HBM
-        # bytes only when the traversal copy does not fit LDS; otherwise they are reported as lds_served and never as HBM traffic.
-        STATE = {"k_round": 268.0, "k_extend": 48.0, "k_shade": 268.0}
+        acc1 = ctx.accel_stats()                                  # after the first frames: the normal records exist now
+        blob_in_lds = acc.BlobBytes <= 40 * 1024                 # kBlobLdsMax: the traversal copy is staged into LDS by every block
+        geometry_in_lds = blob_in_lds and acc1.RoundObjectsInLds > 0 and acc1.RoundRecordsInLds > 0
+        # Algorithmic HBM bytes: what the data layout forces through HBM, nothing that is served from LDS.
+        # Queue bytes of one secondary ray: ray read 32 + path state 48 r + 48 w + next ray written 32 = 160 (the hit stays in registers in
+        # the fused round; the two-kernel form adds hit record 16 w + 16 r: traversal 32 + 16, shading 16 + ray direction 16 + 96 + 32).
+        # Hit geometry, SURVEY 8(d)'s 3 x 32 B vertices + 12 B indices = 108 B: counted ONLY when a hit's shading fetches it from memory --
+        # the fused round kernel on a small scene holds the traversal copy, the object table and the frame's normal records in LDS and
+        # fetches nothing (counting them credited the kernel with bytes it never moved).
+        QUEUE, GEOM, CONTRACT = 160.0, 108.0, 300.0              # CONTRACT: SURVEY 8(d)'s B_state per ray (adds the 32 B hit record round trip), reported apart
+        geom = 0.0 if geometry_in_lds else GEOM
+        STATE = {"k_round": QUEUE + geom, "k_extend": 48.0, "k_shade": QUEUE + GEOM}
         hbm_bvh = 0.0 if blob_in_lds else bvh_bytes_per_ray
 
         def gbps(nbytes, ms):
@@ -344,42 +394,58 @@ def main():
         for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
             if ks.get(key + "_launches", 0):
                 per_ray = STATE[name] + (hbm_bvh if name in ("k_round", "k_extend") else 0.0)
-                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray}
+                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray,
+                                 "contract_bytes": solo_secondary * (CONTRACT + (bvh_bytes_per_ray if name != "k_shade" else 0.0)) if name != "k_extend" else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         kd = kernels[dom]
-        # step level: every byte a frame has to move through HBM by construction of the data layout
-        hit_pixels = W * H                                       # upper bound (camera inside the scene: every primary ray hits on C2)
+        # step level: every byte a frame has to move through HBM by construction of the data layout. Pixels whose primary ray hit:
+        # counted on the device (finite Position.w), not assumed -- the cameras of C3 / C5 see sky.
+        hit_pixels = float(torch.isfinite(lanes[0].renderer.textures["Position"].view(torch.float32).reshape(-1, 4)[:, 3]).sum().item())
+        shade_per_ray = (QUEUE + geom) if "k_round" in kernels else (QUEUE + 32.0 + GEOM)     # two-kernel form: + hit record w + r
         frame_bytes = (W * H * 63.0 + hit_pixels * (47.0 + 48.0 + 48.0 + 32.0)          # G-buffer stores; k_pt_first: G-buffer read, primary-surface record written, the first sample's first bounce shaded in place: state + ray written
-                       + solo_secondary / args.steps * (268.0 + hbm_bvh)                 # traced entries
+                       + solo_secondary / args.steps * (shade_per_ray + hbm_bvh)         # traced entries
                        + hit_pixels * (spp - 1) * (48.0 + 48.0 + 48.0 + 32.0)            # fresh entries of the later samples: primary-surface record, state r + w, first ray written
                        + W * H * 8.0)                                                    # radiance out
+        contract_bytes = solo_secondary / args.steps * (CONTRACT + bvh_bytes_per_ray) + W * H * (63.0 + 8.0 + 32.0)
         step_achieved = gbps(frame_bytes, latency_ms)
-        traffic, traffic_note, valu = None, None, None
+        traffic, traffic_note, valu, lanes_per_instr = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(args.workload, {})
                 if ent.get("source_hash") == source_hash():
-                    traffic = ent.get(dom); valu = ent.get("valu")
+                    traffic = ent.get(dom); valu = ent.get("valu"); lanes_per_instr = ent.get("lanes_per_instruction")
                 else:
                     traffic_note = "profiles/traffic.json was taken from other kernel sources than this build: PMC figures omitted"
             except Exception:
                 traffic = None
         props = torch.cuda.get_device_properties(device)
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+        dom_ms = kd["ms"] / max(1, kd["launches"])
         result["roofline"] = {
             "bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS,
+            # the contract's fields are the DOMINANT KERNEL's: algorithmic bytes per launch / its average launch duration (HIP events on its stream)
+            "achieved": gbps(kd["bytes"], kd["ms"]), "frac": gbps(kd["bytes"], kd["ms"]) / HBM_PEAK_GBS,
             "traffic": traffic,
-            "definition": "achieved = algorithmic HBM bytes of one frame / latency_ms_one_frame (single stream, graph replay); "
-                          "dominant_kernel.* = the same for that kernel alone, from its per-launch HIP events in the single-stream pass",
-            "hbm_bytes_per_frame": frame_bytes, "latency_ms_one_frame": latency_ms,
-            "dominant_kernel": {"name": dom, "avg_launch_ms": kd["ms"] / max(1, kd["launches"]), "launches_timed": kd["launches"],
+            "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "contract_frac": (gbps(kd["contract_bytes"], kd["ms"]) / HBM_PEAK_GBS) if kd.get("contract_bytes") else None,
+            "definition": "achieved = algorithmic HBM bytes per launch of the dominant kernel / its average launch duration (per-launch HIP events on the "
+                          "kernel's stream, single stream, after the timed region); bytes served from LDS are not counted (geometry_served_from); "
+                          "traffic = PMC (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic.json, traffic_frac = that / the same duration; "
+                          "contract_frac = SURVEY 8(d)'s 300 B per ray + BVH bytes wherever they are served from; frame.* = the same for a whole frame",
+            "geometry_served_from": "LDS (object table + normal records staged per launch): not counted" if geometry_in_lds else "memory: 108 B per ray counted",
+            "dominant_kernel": {"name": dom, "avg_launch_ms": dom_ms, "launches_timed": kd["launches"],
                                 "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
+                                "rays_per_launch": solo_secondary / max(1, kd["launches"]),
                                 "achieved": gbps(kd["bytes"], kd["ms"]), "frac": gbps(kd["bytes"], kd["ms"]) / HBM_PEAK_GBS},
-            "other_kernels": {k: {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": gbps(v["bytes"], v["ms"])}
+            "other_kernels": {k: {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": gbps(v["bytes"], v["ms"]),
+                                  "frac": gbps(v["bytes"], v["ms"]) / HBM_PEAK_GBS}
                               for k, v in kernels.items() if k != dom},
+            "frame": {"hbm_bytes_per_frame": frame_bytes, "contract_bytes_per_frame": contract_bytes, "primary_hit_pixels": hit_pixels,
+                      "latency_ms_one_frame": latency_ms, "achieved": step_achieved, "frac": step_achieved / HBM_PEAK_GBS,
+                      "contract_frac": gbps(contract_bytes, latency_ms) / HBM_PEAK_GBS,
+                      "mrays_per_s_one_frame_at_a_time": (solo_secondary + solo_primary) / args.steps / (latency_ms * 1e-3) / 1e6},
             "pipelined": {"frames_in_flight": len(lanes), "ms_per_step": ms_per_step, "achieved": gbps(frame_bytes, ms_per_step),
                           "frac": gbps(frame_bytes, ms_per_step) / HBM_PEAK_GBS},
             "bvh": {"bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / all_rays, "tris_per_ray": cs.TrianglesTested / all_rays,
@@ -388,28 +454,32 @@ def main():
         }
         if traffic_note:
             result["roofline"]["traffic_note"] = traffic_note
-        # VALU issue: wave64 instructions per second against what the chip was MEASURED to issue
-        # (tools/valu_peak.hip -> profiles/r03_valu_peak.json: independent v_fma_f32 streams on every SIMD; a SIMD-32 retires a wave64
-        # instruction in 2 cycles once two or more waves feed it -- round 2 priced against the 4 cycles of a lone wave, i.e. half of this)
+        # VALU issue: wave64 instructions per second against what the chip was MEASURED to issue (tools/valu_peak.hip ->
+        # profiles/r03_valu_peak.json). Two ceilings: independent v_fma_f32 at 8 waves per SIMD (the chip's best), and the mixed stream
+        # (cvt / fma / min / max / cmp / cndmask, the node test's proportions) at the 4 waves per SIMD the render kernels hold -- the
+        # ceiling these kernels can actually reach at their occupancy.
         if valu:
             nominal = props.multi_processor_count * 4 * clock_hz / 2.0
-            peak_issue, peak_at_4, peak_src = nominal, None, "nominal: CUs x 4 SIMD-32 x clock / 2 cycles per wave64 instruction"
+            peak_issue, peak_occ, peak_src = nominal, None, "nominal: CUs x 4 SIMD-32 x clock / 2 cycles per wave64 instruction"
             vp = os.path.join(ROOT, "profiles", "r03_valu_peak.json")
             if os.path.exists(vp):
                 try:
                     vj = json.load(open(vp))
                     peak_issue = vj["fma_indep"]["waves_per_simd_8"] * 1e9
-                    peak_at_4 = vj["fma_indep"]["waves_per_simd_4"] * 1e9
-                    peak_src = "measured, profiles/r03_valu_peak.json: independent v_fma_f32, 8 waves per SIMD, all CUs"
+                    peak_occ = vj["mixed"]["waves_per_simd_4"] * 1e9
+                    peak_src = "measured, profiles/r03_valu_peak.json: fma_indep at 8 waves per SIMD | mixed at 4 waves per SIMD, all CUs"
                 except Exception:
                     pass
-            issued = valu["wave_instructions_per_frame"] / (latency_ms * 1e-3)
-            result["roofline"]["valu_issue"] = {"wave_instructions_per_frame": valu["wave_instructions_per_frame"], "issued_per_s": issued,
-                                                 "peak_per_s": peak_issue, "peak_source": peak_src, "nominal_peak_per_s": nominal,
-                                                 "peak_per_s_at_4_waves_per_simd": peak_at_4, "frac": issued / peak_issue, "clock_hz": clock_hz,
-                                                 "pipelined_frac": valu["wave_instructions_per_frame"] / (ms_per_step * 1e-3) / peak_issue,
-                                                 "note": "SQ_INSTS_VALU of every kernel of a frame (profiles/, same kernel sources) / frame time; the render "
-                                                         "kernels hold 4 waves per SIMD (128 VGPRs)"}
+            per_frame = valu["wave_instructions_per_frame"]
+            alone, piped = per_frame / (latency_ms * 1e-3), per_frame / (ms_per_step * 1e-3)
+            result["roofline"]["valu_issue"] = {
+                "wave_instructions_per_frame": per_frame, "peak_per_s": peak_issue, "peak_per_s_at_occupancy": peak_occ, "peak_source": peak_src,
+                "nominal_peak_per_s": nominal, "clock_hz": clock_hz,
+                "one_frame_at_a_time": {"issued_per_s": alone, "frac": alone / peak_issue, "frac_at_occupancy": alone / peak_occ if peak_occ else None},
+                "pipelined": {"issued_per_s": piped, "frac": piped / peak_issue, "frac_at_occupancy": piped / peak_occ if peak_occ else None},
+                "lanes_per_instruction": lanes_per_instr,
+                "note": "SQ_INSTS_VALU of every kernel of a frame (profiles/, same kernel sources) / frame time; lanes_per_instruction = "
+                        "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) per kernel from the same PMC files"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.emulate_world and not dynamic:
         result["cpu_baseline"] = cpu_baseline(scene, gs, W, H, L, args.cpu_budget)
 

@@ -465,6 +465,9 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     c.tlasBlasIds = pieceIds;
     if (objectEnd != c.tlasObjectEnd || count != c.tlasValidatedCount || bindingHash != c.tlasBindingHash) c.validated = false;     // same instances of the same bottom levels over the same objects: nothing new to check
     c.tlasObjectEnd = objectEnd; c.tlasValidatedCount = count; c.tlasBindingHash = bindingHash;
+    // the same instances of the same bottom levels over the same objects (a dynamic frame's rebuild after a refit): the verdict of the
+    // shared-geometry check still holds, and with it the frame's normal records (drop_tlas had put them aside with the old top level)
+    c.normalsShared = c.validated && c.sharedVerdict;
     c.haveTlas = true;
     return PT_OK;
 }
@@ -515,6 +518,9 @@ int pt_get_accel_stats(PtContext* ctx, PtAccelStats* out)
     for (auto& kv : c.blas) { nb += (uint64_t)kv.second.nodeCount * sizeof(WideNode); tb += (uint64_t)kv.second.triCount * sizeof(TriPacket); out->MaxBottomLevelDepth = std::max(out->MaxBottomLevelDepth, kv.second.depth); }
     out->BlobBytes = c.sceneOwner ? 0 : c.blob.bytes;          // a view holds no memory of its own
     out->SharedScene = c.sceneOwner ? 1u : 0u;
+    out->NormalRecords = c.normalsShared ? 1u : 0u;
+    out->RoundObjectsInLds = round_objects_in_lds(c, c.objectCount, c.shadeGeomDev != nullptr);
+    out->RoundRecordsInLds = round_records_in_lds(c, c.objectCount, c.shadeGeomDev != nullptr);
     if (c.tlasHeaderHost && !c.tlasHeaderPending) out->TopLevelDepth = c.tlasHeaderHost->depth;
     out->NodeBytes = nb; out->TriangleBytes = tb;
     return PT_OK;
@@ -540,6 +546,12 @@ int pt_set_object_data(PtContext* ctx, const PtObjectData* device_objects, uint3
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     API_ARG(&ctx->c, device_objects || count == 0, "device_objects is NULL");
     ctx->c.objects = device_objects; ctx->c.objectCount = count;
+    return PT_OK;
+}
+int pt_invalidate_object_data(PtContext* ctx)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    ctx->c.validated = false; ctx->c.normalsShared = false; ctx->c.sharedVerdict = false;   // the next render resolves VertexDesc / MeshDescriptors again (validate_scene)
     return PT_OK;
 }
 int pt_set_instance_data(PtContext* ctx, const PtInstanceData* device_instances, uint32_t count)
@@ -621,7 +633,8 @@ static int validate_scene(Context& c)
         }
     }
     c.validated = true; c.validatedObjects = c.objects; c.validatedObjectCount = c.objectCount;
-    c.normalsShared = c.objectCount != 0 && c.blasTableDev != nullptr && sharedMismatch == 0;
+    c.sharedVerdict = c.objectCount != 0 && c.blasTableDev != nullptr && sharedMismatch == 0;
+    c.normalsShared = c.sharedVerdict;
     return PT_OK;
 }
 

@@ -175,33 +175,54 @@ int pt_gather_bands(PtContext* ctx, const void* local_bands, void* dst_full, uin
     if (!local_bands || (me == root && !dst_full)) return fail(&c, PT_ERROR_INVALID_ARGUMENT, "pt_gather_bands: a buffer is NULL");
     const uint64_t rowBytes = (uint64_t)width * pixel_bytes;
     if (rowBytes == 0 || rowBytes % 16 != 0) return fail(&c, PT_ERROR_INVALID_ARGUMENT, "pt_gather_bands: a row must be a multiple of 16 bytes");
-    const bool exchange = N > 1 && !(c.debugFlags & PT_DEBUG_GATHER_LOCAL_ONLY);
+    // PT_DEBUG_GATHER_SELF_EXCHANGE (rehearsal on ONE GPU, world-size-1 communicator): the rank's own bands -- whoever the sharding says it
+    // is -- take the path a foreign band takes: ncclSend to itself and ncclRecv from itself, one pair per band inside one group, the
+    // receive aimed straight at the band's rows of the full frame. The plan arithmetic, the grouped p2p calls, ncclGroupEnd and RCCL's
+    // kernel on the context's stream all really run; only the peer is the sender itself.
+    const bool selfExchange = (c.debugFlags & PT_DEBUG_GATHER_SELF_EXCHANGE) != 0;
+    const bool exchange = !selfExchange && N > 1 && !(c.debugFlags & PT_DEBUG_GATHER_LOCAL_ONLY);
+    if (selfExchange && (!c.comm || c.commWorld != 1))
+        return fail(&c, PT_ERROR_NOT_READY, "pt_gather_bands: PT_DEBUG_GATHER_SELF_EXCHANGE needs a communicator of world size 1");
     if (exchange && (!c.comm || c.commWorld != N || c.commRank != me))
         return fail(&c, PT_ERROR_NOT_READY, "pt_gather_bands: no communicator matching the sharding (pt_comm_init / pt_comm_adopt with the rank and rank count of pt_set_sharding)");
     if (hipSetDevice(c.device) != hipSuccess) return fail(&c, PT_ERROR_HIP, "hipSetDevice");
     uint32_t localRows = 0;
     pt_local_rows(&sh, height, &localRows);
 
-    if (exchange) {
+    if (exchange || selfExchange) {
         int s; const Rccl* R = rccl(&c, s);
         if (!R) return s;
-        uint32_t count = 0;
-        pt_gather_plan(&sh, height, rowBytes, root, nullptr, 0, &count);
-        std::vector<PtBandMessage> plan(count);
-        pt_gather_plan(&sh, height, rowBytes, root, plan.data(), count, &count);
+        std::vector<PtBandMessage> plan;
+        if (selfExchange) {
+            if (!dst_full) return fail(&c, PT_ERROR_INVALID_ARGUMENT, "pt_gather_bands: a buffer is NULL");
+            // the messages a root would RECEIVE from rank `me`: pt_gather_plan seen from a root that is not `me`; when N == 1 (or every
+            // other rank would be `me` too) the bands are listed directly
+            const uint32_t bands = (height + BH - 1) / BH;
+            for (uint32_t b = me; b < bands; b += N) {
+                const uint32_t y0 = b * BH, rows = height - y0 < BH ? height - y0 : BH;
+                PtBandMessage m{}; m.Peer = 0; m.IsSend = 1u; m.Band = b;
+                m.LocalOffset = (uint64_t)(b / N) * BH * rowBytes; m.FullOffset = (uint64_t)y0 * rowBytes; m.Bytes = (uint64_t)rows * rowBytes;
+                plan.push_back(m);
+            }
+        } else {
+            uint32_t count = 0;
+            pt_gather_plan(&sh, height, rowBytes, root, nullptr, 0, &count);
+            plan.resize(count);
+            pt_gather_plan(&sh, height, rowBytes, root, plan.data(), count, &count);
+        }
         ncclComm_t comm = (ncclComm_t)c.comm;
         API_NCCL(&c, R, R->GroupStart());
         ncclResult_t r = ncclSuccess;
         for (const PtBandMessage& m : plan) {
             if (m.IsSend) r = R->Send((const uint8_t*)local_bands + m.LocalOffset, (size_t)m.Bytes, ncclUint8, (int)m.Peer, comm, c.stream);
-            else r = R->Recv((uint8_t*)dst_full + m.FullOffset, (size_t)m.Bytes, ncclUint8, (int)m.Peer, comm, c.stream);
+            if (r == ncclSuccess && (!m.IsSend || selfExchange)) r = R->Recv((uint8_t*)dst_full + m.FullOffset, (size_t)m.Bytes, ncclUint8, (int)m.Peer, comm, c.stream);
             if (r != ncclSuccess) break;
         }
         const ncclResult_t e = R->GroupEnd();
         if (r != ncclSuccess) return fail(&c, PT_ERROR_RCCL, std::string("ncclSend / ncclRecv: ") + R->GetErrorString(r));
         if (e != ncclSuccess) return fail(&c, PT_ERROR_RCCL, std::string("ncclGroupEnd: ") + R->GetErrorString(e));
     }
-    if (me == root && localRows && local_bands != dst_full) {
+    if (!selfExchange && me == root && localRows && local_bands != dst_full) {
         const uint32_t row16 = (uint32_t)(rowBytes / 16);
         const uint64_t total = (uint64_t)localRows * row16;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);

@@ -143,6 +143,7 @@ struct Context {
     const BlasEntry* blasTableDev = nullptr; uint32_t blasTableCount = 0; uint32_t blasTableMaxTris = 0;    // the top-level build's table of bottom levels (device; a viewer: the owner's)
     const InstanceSource* instSourceDev = nullptr;
     bool normalsShared = false;              // every instance of a bottom level resolves to the same vertex buffer / stride / normal offset (checked with the objects)
+    bool sharedVerdict = false;              // what the last shared-geometry check said (normalsShared is put aside while there is no top level)
     bool validated = false; uint32_t* validateDev = nullptr;   // descriptor / index validation of the scene inputs (pt_api.hip make_views)
     const void* validatedObjects = nullptr; uint32_t validatedObjectCount = 0;
 
@@ -199,6 +200,8 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out);
 hipError_t launch_bsdf_evaluate(hipStream_t stream, const float* q, uint32_t count, float* r);
 hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap);
+uint32_t round_objects_in_lds(const Context& c, uint32_t objectCount, bool haveShadeGeom);   // the fused round kernel's LDS tables (PtAccelStats)
+uint32_t round_records_in_lds(const Context& c, uint32_t objectCount, bool haveShadeGeom);
 inline bool normal_records_usable(const Context& c) { return c.normalsShared && c.blasTableDev && c.blasTableCount <= 65535u /* grid.y of k_capture_normals */ && c.shadeRecA && c.blob.triCount && c.blob.triCount <= c.shadeRecCap; }
 hipError_t launch_check_shared_geometry(hipStream_t stream, const InstanceSource* src, const BlasEntry* table, uint32_t n, const ShadeGeom* shadeGeom, uint32_t* out);
 hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom);

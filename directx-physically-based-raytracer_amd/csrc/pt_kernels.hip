@@ -730,22 +730,24 @@ static void timing_end(Context& c, std::vector<hipEvent_t>& ev, uint32_t k) { if
 // Objects whose resolved geometry + material k_round stages in LDS behind the blob: all of them, if that does not cost the kernel its fourth
 // workgroup per CU (160 KB / 4, the kernel's static words and the 512-byte allocation granule counted); otherwise none.
 static uint32_t lds_bytes_of_records(uint32_t n) { return (n * 20u + 15u) / 16u * 16u; }
-static uint32_t round_objects_in_lds(const Context& c, const SceneView& sv)
+uint32_t round_objects_in_lds(const Context& c, uint32_t objectCount, bool haveShadeGeom)
 {
-    if (c.blob.bytes > kBlobLdsMax || !sv.objectCount || !sv.shadeGeom) return 0u;
+    if (c.blob.bytes > kBlobLdsMax || !objectCount || !haveShadeGeom) return 0u;
     const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
-    const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + sv.objectCount * kObjLds16 * 16u + 128u;
-    return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? sv.objectCount : 0u;
+    const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + objectCount * kObjLds16 * 16u + 128u;
+    return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? objectCount : 0u;
 }
+static uint32_t round_objects_in_lds(const Context& c, const SceneView& sv) { return round_objects_in_lds(c, sv.objectCount, sv.shadeGeom != nullptr); }
 // ... and the frame's normal records behind them, under the same rule
-static uint32_t round_records_in_lds(const Context& c, const SceneView& sv)
+uint32_t round_records_in_lds(const Context& c, uint32_t objectCount, bool haveShadeGeom)
 {
-    const uint32_t nobj = round_objects_in_lds(c, sv);
+    const uint32_t nobj = round_objects_in_lds(c, objectCount, haveShadeGeom);
     if (!nobj || !normal_records_usable(c)) return 0u;
     const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
     const uint32_t bytes = (flat ? kFlatLdsFixed : kExtendLdsFixed) + c.blob.bytes + nobj * kObjLds16 * 16u + lds_bytes_of_records(c.blob.triCount) + 128u;
     return (bytes + 511u) / 512u * 512u <= 160u * 1024u / 4u ? c.blob.triCount : 0u;
 }
+static uint32_t round_records_in_lds(const Context& c, const SceneView& sv) { return round_records_in_lds(c, sv.objectCount, sv.shadeGeom != nullptr); }
 
 // the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
 static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
@@ -911,7 +913,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
 
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
     const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
-                           (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP)) == 0;   // counters / validation variants launch directly
+                           (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP | PT_DEBUG_GATHER_LOCAL_ONLY | PT_DEBUG_GATHER_SELF_EXCHANGE)) == 0;   // counters / validation variants launch directly
     if (graphable) {
         if (key != c.graphKey || !c.graphExec) {
             if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }

@@ -12,9 +12,12 @@
 // The scene construction mirrors scenes.py:cornell_box(variant="ggx") value for value (same double-precision
 // expressions), so both hosts feed the library identical bytes. Build: make -C ../csrc ../pt_demo (hipcc, host code).
 #include <hip/hip_runtime.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -108,14 +111,19 @@ template <typename T> static T* upload(const std::vector<T>& v)
     return d;
 }
 
-// --ranks R: start one child per rank and wait for them (no GPU call has been made in this process, and none will be)
+// --ranks R: start one child per rank and wait for them (no GPU call has been made in this process, and none will be).
+// The unique id travels through a file in a directory of our own (mkdtemp: mode 0700, unpredictable name). The first rank that fails
+// ends the run: the others would wait for it inside ncclCommInitRank or a grouped receive for ever, so they are killed.
 static int launch_ranks(int argc, char** argv, uint32_t ranks)
 {
-    const std::string idFile = "/tmp/pt_demo_id_" + std::to_string((long)getpid());
+    char dirTemplate[] = "/tmp/pt_demo_XXXXXX";
+    if (!mkdtemp(dirTemplate)) { perror("mkdtemp"); return 2; }
+    const std::string dir = dirTemplate, idFile = dir + "/id";
     std::vector<pid_t> pids;
-    for (uint32_t r = 0; r < ranks; r++) {
+    int rc = 0;
+    for (uint32_t r = 0; r < ranks && rc == 0; r++) {
         const pid_t pid = fork();
-        if (pid < 0) { perror("fork"); return 2; }
+        if (pid < 0) { perror("fork"); rc = 2; break; }
         if (pid == 0) {
             std::vector<std::string> args(argv, argv + argc);
             for (const char* extra : { "--rank", "", "--world", "", "--id-file", "" }) args.push_back(extra);
@@ -128,9 +136,21 @@ static int launch_ranks(int argc, char** argv, uint32_t ranks)
         }
         pids.push_back(pid);
     }
-    int rc = 0;
-    for (pid_t p : pids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = WIFEXITED(st) ? WEXITSTATUS(st) : 2; }
-    unlink(idFile.c_str());
+    size_t left = pids.size();
+    while (left) {
+        int st = 0;
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) { if (errno == EINTR) continue; break; }
+        auto it = std::find(pids.begin(), pids.end(), p);
+        if (it == pids.end()) continue;
+        *it = -1; left--;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 2;
+        if (code != 0 && rc == 0) {
+            rc = code;
+            for (pid_t q : pids) if (q > 0) kill(q, SIGTERM);                     // exactly the children started above
+        }
+    }
+    unlink((idFile + ".tmp").c_str()); unlink(idFile.c_str()); rmdir(dir.c_str());
     return rc;
 }
 

@@ -21,7 +21,7 @@ _LIB = None
 EXPORTS = [
     "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync", "pt_set_frames_in_flight",
     "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
-    "pt_build_top_level", "pt_get_accel_stats", "pt_share_scene", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data",
+    "pt_build_top_level", "pt_get_accel_stats", "pt_share_scene", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data", "pt_invalidate_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
     "pt_comm_get_unique_id", "pt_comm_init", "pt_comm_adopt", "pt_comm_destroy", "pt_gather_bands", "pt_gather_plan",
     "pt_raytrace_set_constants", "pt_raytrace_render", "pt_trace_visibility", "pt_bsdf_evaluate", "pt_reset_counters", "pt_get_counters",
@@ -79,7 +79,8 @@ class AccelStats(C.Structure):
     _fields_ = [("InstanceCount", C.c_uint32), ("BottomLevelCount", C.c_uint32), ("TriangleCount", C.c_uint64),
                 ("NodeBytes", C.c_uint64), ("TriangleBytes", C.c_uint64), ("NodeSizeBytes", C.c_uint32),
                 ("TriangleSizeBytes", C.c_uint32), ("MaxBottomLevelDepth", C.c_uint32), ("TopLevelDepth", C.c_uint32),
-                ("BlobBytes", C.c_uint64), ("SharedScene", C.c_uint32), ("_pad", C.c_uint32)]
+                ("BlobBytes", C.c_uint64), ("SharedScene", C.c_uint32), ("NormalRecords", C.c_uint32),
+                ("RoundObjectsInLds", C.c_uint32), ("RoundRecordsInLds", C.c_uint32)]
 
 
 def load_library():
@@ -115,6 +116,7 @@ def load_library():
             f.argtypes = [C.c_void_p, C.c_void_p]
         lib.pt_set_object_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         lib.pt_set_instance_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        lib.pt_invalidate_object_data.argtypes = [C.c_void_p]
         lib.pt_local_rows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         lib.pt_deinterleave_bands.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_uint32]
@@ -211,6 +213,10 @@ class DeviceContext:
 
     def set_debug_flags(self, flags):
         self.check(self.lib.pt_set_debug_flags(self.handle, flags))
+
+    def invalidate_object_data(self):
+        """VertexDesc / MeshDescriptors of the bound ObjectData were rewritten in place: resolve and check them again at the next render."""
+        self.check(self.lib.pt_invalidate_object_data(self.handle))
 
     def enable_kernel_timing(self, on=True):
         self.check(self.lib.pt_enable_kernel_timing(self.handle, 1 if on else 0))

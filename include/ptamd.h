@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTAMD_ABI_VERSION 3
+#define PTAMD_ABI_VERSION 4
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -256,7 +256,11 @@ typedef struct PtAccelStats {
     uint32_t NodeSizeBytes, TriangleSizeBytes;   /* 80 (compressed 8-wide node) / 48 */
     uint32_t MaxBottomLevelDepth, TopLevelDepth; /* levels of 8-wide nodes */
     uint64_t BlobBytes;                   /* the traversal copy: instances + every referenced bottom level + top level (0 for a view) */
-    uint32_t SharedScene, _pad;           /* 1: this context views another context's scene (pt_share_scene) */
+    uint32_t SharedScene;                 /* 1: this context views another context's scene (pt_share_scene) */
+    uint32_t NormalRecords;               /* 1: hits take their vertex normals from the frame's normal records (every instance of a bottom level names the same
+                                             vertex data; decided when the object data is resolved), 0: fetched through the hit's own object */
+    uint32_t RoundObjectsInLds, RoundRecordsInLds;   /* what the fused round kernel stages in LDS behind the traversal copy: objects (resolved geometry + material) |
+                                                        normal records; 0 = none: a hit's shading then fetches them from memory (measurement: which bytes reach HBM) */
 } PtAccelStats;
 int  pt_get_accel_stats(PtContext* ctx, PtAccelStats* out);           /* synchronises */
 
@@ -273,8 +277,14 @@ int  pt_share_scene(PtContext* ctx, PtContext* source);
 int  pt_set_camera(PtContext* ctx, const PtCamera* camera);                          /* host struct, copied */
 int  pt_set_scene_data(PtContext* ctx, const PtSceneData* scene_data);               /* host struct, copied */
 /* device array, referenced. Material and TextureMapInfoArray are read at every hit; VertexDesc and MeshDescriptors are resolved (and
- * checked against the descriptor heap) when the binding -- pointer or count --, the heap or the top level changes: rebind after rewriting them in place. */
+ * checked against the descriptor heap) when the binding -- pointer or count --, the heap or the instances of the top level change, and
+ * after pt_invalidate_object_data. Binding the same pointer and count again (a host that fills its GPUBuffers slots before every Render,
+ * Source/App.cpp:540-561) is free and resolves nothing: a caller that REWRITES VertexDesc / MeshDescriptors of a bound array in place says
+ * so with pt_invalidate_object_data, and the next render resolves and checks them again (one small kernel + one wait).
+ * MeshDescriptors.Indices is checked but not dereferenced at a hit: a triangle's vertex indices are those of the index buffer given to
+ * pt_build_bottom_level (kept next to its triangle packets), as DXR itself intersects the triangles of the build-time index buffer. */
 int  pt_set_object_data(PtContext* ctx, const PtObjectData* device_objects, uint32_t count);
+int  pt_invalidate_object_data(PtContext* ctx);
 int  pt_set_instance_data(PtContext* ctx, const PtInstanceData* device_instances, uint32_t count); /* device array, referenced */
 
 /* Multi-GPU framebuffer sharding (not a reference feature). The frame is cut into
@@ -376,6 +386,8 @@ int  pt_get_counters(PtContext* ctx, PtCounters* out);
 #define PT_DEBUG_LOCKSTEP        0x20u    /* scenes too large for LDS: the lock-step schedules (one tile of rays per wave) instead of the streaming form */
 #define PT_DEBUG_GATHER_LOCAL_ONLY 0x40u  /* pt_gather_bands places the root's own bands and exchanges nothing: lets ONE GPU play every rank in turn (tests) */
 #define PT_DEBUG_BRUTE_FORCE     0x2u     /* bounce rays test every triangle of every instance (validates the LBVH) */
+#define PT_DEBUG_GATHER_SELF_EXCHANGE 0x80u /* pt_gather_bands with a world-size-1 communicator: the rank's own bands travel by ncclSend to itself + ncclRecv from
+                                             itself (one pair per band, one group) into the full frame -- the grouped p2p path of a real gather on ONE GPU (tests, bench --rehearse-collective) */
 int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
 int  pt_debug_read_mismatch(PtContext* ctx, float* out16);

@@ -1352,10 +1352,13 @@ uint64_t or_gbuffer_render(const OrScene* s, const OrCamera* cam, const OrSceneD
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
+    /* work items are 64-pixel pieces of a scanline, not whole scanlines: a bounded slab of rows (bench.py cpu_baseline) has fewer rows
+     * than a big host has threads. Pixels are independent, the order changes nothing. */
+    const int64_t cpr = ((int64_t)W + 63) / 64, nchunks = (y1 > y0 ? (int64_t)(y1 - y0) : 0) * cpr;
     #pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t yy = (int64_t)y0; yy < (int64_t)y1; yy++) {
-        uint32_t y = (uint32_t)yy;
-        for (uint32_t x = 0; x < W; x++) {
+    for (int64_t cc = 0; cc < nchunks; cc++) {
+        const uint32_t y = y0 + (uint32_t)(cc / cpr), x0 = (uint32_t)(cc % cpr) * 64u, x1 = x0 + 64u < W ? x0 + 64u : W;
+        for (uint32_t x = x0; x < x1; x++) {
             size_t pi = (size_t)y * W + x;
             float Position[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
             float LinearDepth = INFINITY, NormalizedDepth = cam->IsNormalizedDepthReversed ? 0.0f : 1.0f;
@@ -1489,10 +1492,11 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
+    const int64_t cpr = ((int64_t)W + 63) / 64, nchunks = (y1 > y0 ? (int64_t)(y1 - y0) : 0) * cpr;    /* 64-pixel pieces of a scanline, as in or_gbuffer_render */
     #pragma omp parallel for schedule(dynamic, 1) reduction(+ : total_rays)
-    for (int64_t yy = (int64_t)y0; yy < (int64_t)y1; yy++) {
-        uint32_t y = (uint32_t)yy;
-        for (uint32_t x = 0; x < W; x++) {
+    for (int64_t cc = 0; cc < nchunks; cc++) {
+        const uint32_t y = y0 + (uint32_t)(cc / cpr), x0 = (uint32_t)(cc % cpr) * 64u, x1 = x0 + 64u < W ? x0 + 64u : W;
+        for (uint32_t x = x0; x < x1; x++) {
             size_t pi = (size_t)y * W + x;
             uint32_t rng = or_rng_init(x, y, gs->FrameIndex);                           /* :108 */
             float uv[2];

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(ptamd):
     for n in names:
         assert hasattr(lib, n), f"libptamd.so does not export {n}"
     assert sorted(ptamd.EXPORTS) == names                       # the Python binding covers the whole header
-    assert lib.pt_abi_version() == 3
+    assert lib.pt_abi_version() == 4
 
 
 def test_struct_sizes_match_reference_layouts(pkg, ptamd):

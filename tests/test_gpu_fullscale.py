@@ -1,5 +1,6 @@
-"""GPU tests (-m gpu) of the three big BASELINE.json configs AT THEIR REAL SCALE, against the oracle:
+"""GPU tests (-m gpu) of the BASELINE.json configs AT THEIR REAL SCALE, against the oracle:
 
+  C2  Cornell box 1920x1080, 4 spp, 8 bounces, full GGX metallic-roughness (the headline configuration)
   C3  Sponza-scale mesh, 250 632 triangles in one BLAS, 1920x1080, 1 spp, 8 bounces + Russian roulette
   C5  10 000 instances of a 320-triangle mesh (two-level BVH) + ground + light, 1920x1080, 4 spp, 8 bounces
   C4  Cornell box 3840x2160, 16 spp, 16 bounces, as one rank-of-8 shard and as the whole frame
@@ -89,6 +90,19 @@ def full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band, band_index, exac
     assert cp.PrimaryRays + cp.SecondaryRays == ref_rays                                       # identical path structure in the band
     check_band(part, ref_gb, ref_f32, exact)
     return full, cf
+
+
+def test_c2_cornell_1080p_4spp_8_bounces(gpu, ptamd, oracle, pkg):
+    """BASELINE configs[1], the configuration the headline metric is quoted on, at its real size against the oracle (it
+    was the one full-size configuration checked by properties only): two 16-row bands -- one through the tall mirror box and the glossy
+    short box, one near the ceiling light -- bit for bit, ray counts equal."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 1920, 1080
+    scene = S.cornell_box(aspect=W / H, variant="ggx")
+    gs = S.graphics_settings(W, H, spp=4, bounces=8)
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=16, band_index=38, exact=True)
+    assert cf.PrimaryRays == W * H and np.all(np.isfinite(full["Position"][..., 3]))
+    full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=16, band_index=9, exact=True)
 
 
 def test_c3_sponza_scale_250k_triangles_1080p(gpu, ptamd, oracle, pkg):

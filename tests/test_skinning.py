@@ -129,6 +129,9 @@ def test_dynamic_frames_enqueued_without_synchronisation(gpu, ptamd, oracle, pkg
         g.UpdateAccelerationStructures(2)
         r.render(S.graphics_settings(W, H, spp=1, bounces=2, frame_index=k))
     gpu.sync()
+    # a refit used to cost a dynamic scene its normal records for good (drop_tlas put them aside, and the rebuild of an unchanged
+    # binding never brought them back)
+    assert gpu.accel_stats().NormalRecords == 1
     for k, pose in enumerate(poses):                                         # the oracle skins the same sequence (skinning reads the previous position)
         oracle_skin(oracle, bar, pose)
         assert np.array_equal(snapshots[k].cpu().numpy(), bar.vertices.view(np.uint8).reshape(-1)), f"frame {k} was skinned with another frame's pose"

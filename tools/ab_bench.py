@@ -1,5 +1,6 @@
 """Developer helper: time one workload with a given build of libptamd (tools/ab.sh), one process per build.
-usage: tools/ab_bench.py [--workloads c3,c5] [--frames 12] [name ...]      (no name: every build/ab/libptamd_*.so)"""
+usage: tools/ab_bench.py [--workloads c3,c5] [--frames 12] [--log gpurun_out/ab/<experiment>.jsonl] [name ...]      (no name: every build/ab/libptamd_*.so)
+Every result is also appended as one JSON line to --log (default gpurun_out/ab/ab.jsonl): the A/B evidence copied into profiles/r04_ab/."""
 import argparse, glob, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -45,6 +46,8 @@ if __name__ == "__main__":
     ap.add_argument("--workloads", default="c3,c5")
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--inflight", type=int, default=3)
+    ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "ab", "ab.jsonl"))
+    ap.add_argument("--note", default="")
     ap.add_argument("names", nargs="*")
     a = ap.parse_args()
     if a.child is not None:
@@ -60,5 +63,9 @@ if __name__ == "__main__":
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if line:
                 d = json.loads(line[-1]); print(f"{w} {name:28s} {d['mrays']:9.1f} Mrays/s  {d['ms']:7.3f} ms/frame", flush=True)
+                os.makedirs(os.path.dirname(a.log), exist_ok=True)
+                with open(a.log, "a") as fh:
+                    fh.write(json.dumps({"workload": w, "build": name, "mrays_per_s": d["mrays"], "ms_per_frame": d["ms"], "frames": a.frames,
+                                         "inflight": a.inflight, "note": a.note, "time": time.strftime("%Y-%m-%dT%H:%M:%S")}) + "\n")
             else:
                 print(w, name, "FAILED", p.stderr[-300:], flush=True)
