@@ -35,6 +35,8 @@ WORKLOADS = {
     # name: (scene factory kwargs, width, height, spp, bounces, description)
     "c2": ("cornell", 1920, 1080, 4, 8, "Cornell Box 1920x1080 4spp 8 bounces full GGX metallic-roughness (BASELINE configs[1])"),
     "c3": ("sponza", 1920, 1080, 1, 8, "Sponza-scale ~250k tris 1920x1080 1spp 8 bounces + RR (BASELINE configs[2])"),
+    # BASELINE configs[2] says "Sponza-scale glTF": the same mesh with what a glTF import brings -- UVs, tangents, three 1024^2 textures per material, alpha-masked strips
+    "c3t": ("sponza_textured", 1920, 1080, 1, 8, "Sponza-scale ~250k tris, 24 textured materials (base colour + normal + metallic-roughness, 1024^2 RGBA8 each), 11.9 % of the triangles alpha-masked, 1920x1080 1spp 8 bounces + RR"),
     "c4": ("cornell", 3840, 2160, 16, 16, "Cornell Box 3840x2160 16spp 16 bounces (BASELINE configs[3])"),
     "c5": ("grid", 1920, 1080, 4, 8, "10k instances two-level BVH 1920x1080 4spp 8 bounces (BASELINE configs[4])"),
     "c1": ("cornell_lambert", 256, 256, 1, 2, "Cornell Box 256x256 1spp 2 bounces Lambertian only (BASELINE configs[0])"),
@@ -61,6 +63,8 @@ def make_scene(kind, aspect, S):
         return S.cornell_box(aspect=aspect, variant="diffuse"), 1
     if kind == "sponza":
         return S.sponza_scale(aspect=aspect), 0
+    if kind == "sponza_textured":
+        return S.sponza_scale(aspect=aspect, textured=True), 0
     if kind == "grid":
         return S.instanced_grid(n=100, aspect=aspect), 0
     if kind == "dynamic":
@@ -390,21 +394,26 @@ def main():
         def gbps(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
+        # Pixels whose primary ray hit: counted on the device (finite Position.w), not assumed -- the cameras of C3 / C5 see sky.
+        hit_pixels = float(torch.isfinite(lanes[0].renderer.textures["Position"].view(torch.float32).reshape(-1, 4)[:, 3]).sum().item())
+        # the shading kernel of a round (k_round, or k_shade in the two-kernel form) also restarts the paths whose sample ended: one fresh
+        # entry per primary-hit pixel and sample after the first over a frame -- primary-surface record 48 r, state 48 r + 48 w, first ray 32 w
+        FRESH = 48.0 + 48.0 + 48.0 + 32.0
+        fresh_entries = hit_pixels * (spp - 1) * args.steps     # over the timed single-stream pass
         kernels = {}
         for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
             if ks.get(key + "_launches", 0):
                 per_ray = STATE[name] + (hbm_bvh if name in ("k_round", "k_extend") else 0.0)
-                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray,
-                                 "contract_bytes": solo_secondary * (CONTRACT + (bvh_bytes_per_ray if name != "k_shade" else 0.0)) if name != "k_extend" else None}
+                fresh = fresh_entries * FRESH if name in ("k_round", "k_shade") else 0.0
+                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray + fresh,
+                                 "contract_bytes": solo_secondary * (CONTRACT + (bvh_bytes_per_ray if name != "k_shade" else 0.0)) + fresh if name != "k_extend" else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         kd = kernels[dom]
-        # step level: every byte a frame has to move through HBM by construction of the data layout. Pixels whose primary ray hit:
-        # counted on the device (finite Position.w), not assumed -- the cameras of C3 / C5 see sky.
-        hit_pixels = float(torch.isfinite(lanes[0].renderer.textures["Position"].view(torch.float32).reshape(-1, 4)[:, 3]).sum().item())
+        # step level: every byte a frame has to move through HBM by construction of the data layout
         shade_per_ray = (QUEUE + geom) if "k_round" in kernels else (QUEUE + 32.0 + GEOM)     # two-kernel form: + hit record w + r
         frame_bytes = (W * H * 63.0 + hit_pixels * (47.0 + 48.0 + 48.0 + 32.0)          # G-buffer stores; k_pt_first: G-buffer read, primary-surface record written, the first sample's first bounce shaded in place: state + ray written
                        + solo_secondary / args.steps * (shade_per_ray + hbm_bvh)         # traced entries
-                       + hit_pixels * (spp - 1) * (48.0 + 48.0 + 48.0 + 32.0)            # fresh entries of the later samples: primary-surface record, state r + w, first ray written
+                       + hit_pixels * (spp - 1) * FRESH                                  # fresh entries of the later samples
                        + W * H * 8.0)                                                    # radiance out
         contract_bytes = solo_secondary / args.steps * (CONTRACT + bvh_bytes_per_ray) + W * H * (63.0 + 8.0 + 32.0)
         step_achieved = gbps(frame_bytes, latency_ms)
@@ -438,6 +447,7 @@ def main():
             "dominant_kernel": {"name": dom, "avg_launch_ms": dom_ms, "launches_timed": kd["launches"],
                                 "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
                                 "rays_per_launch": solo_secondary / max(1, kd["launches"]),
+                                "fresh_entries_per_launch": (fresh_entries / max(1, kd["launches"])) if dom in ("k_round", "k_shade") else 0.0,
                                 "achieved": gbps(kd["bytes"], kd["ms"]), "frac": gbps(kd["bytes"], kd["ms"]) / HBM_PEAK_GBS},
             "other_kernels": {k: {"avg_launch_ms": v["ms"] / max(1, v["launches"]), "launches_timed": v["launches"], "achieved": gbps(v["bytes"], v["ms"]),
                                   "frac": gbps(v["bytes"], v["ms"]) / HBM_PEAK_GBS}

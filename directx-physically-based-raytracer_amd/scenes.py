@@ -490,9 +490,43 @@ def dynamic_scene(aspect=16 / 9):
     return Scene(nodes, objects, cam, make_scene_data((0.05, 0.06, 0.08, 1), is_static=False), name="dynamic").finalize()
 
 
-def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24):
-    """~250k-triangle displaced terrain + column grid in ONE BLAS (config C3); materials vary per strip."""
+def _material_textures(rng, size, masked):
+    """Procedural RGBA8 texture set of one glTF-style material (Source/GLTFHelpers.ixx:370-428): base colour (sRGB; alpha is a lattice with
+    a quarter of its cells cut out when the material is alpha-masked), tangent-space normal map, packed metallic-roughness (G = roughness,
+    B = metallic, as GLTFHelpers.ixx reads them). Smooth low-frequency patterns plus texel noise, so neighbouring hits fetch neighbouring texels."""
+    y, x = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    f = rng.integers(2, 9, 4)
+    ph = rng.random(4) * 6.28
+    wave = 0.5 + 0.5 * np.sin(2 * np.pi * f[0] * x + ph[0]) * np.cos(2 * np.pi * f[1] * y + ph[1])
+    tint = 0.35 + 0.6 * rng.random(3)
+    base = np.zeros((size, size, 4), np.uint8)
+    noise = rng.integers(0, 24, (size, size), dtype=np.uint8)
+    for c in range(3):
+        base[..., c] = np.clip((0.35 + 0.65 * wave) * tint[c] * 255.0, 0, 231).astype(np.uint8) + noise
+    base[..., 3] = 255
+    if masked:
+        cells = 48
+        cut = (((x * cells).astype(np.int32) % 2 == 0) & ((y * cells).astype(np.int32) % 2 == 0))
+        base[..., 3] = np.where(cut, 0, 255)
+    nm = np.zeros((size, size, 4), np.uint8)
+    nm[..., 0] = np.clip((0.5 + 0.18 * np.sin(2 * np.pi * f[2] * 4 * x + ph[2])) * 255.0, 0, 255)
+    nm[..., 1] = np.clip((0.5 + 0.18 * np.cos(2 * np.pi * f[3] * 4 * y + ph[3])) * 255.0, 0, 255)
+    nm[..., 2] = 255; nm[..., 3] = 255
+    mr = np.zeros((size, size, 4), np.uint8)
+    mr[..., 1] = np.clip((0.15 + 0.7 * wave) * 255.0, 0, 255)
+    mr[..., 2] = np.where(np.sin(2 * np.pi * f[0] * 0.5 * (x + y) + ph[1]) > 0.6, 255, 0)
+    mr[..., 3] = 255
+    return Texture(base, srgb=True), Texture(nm), Texture(mr)
+
+
+def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24, textured=False, texture_size=1024, masked_strips=(3, 12, 20)):
+    """~250k-triangle displaced terrain + column grid in ONE BLAS (config C3); materials vary per strip.
+    textured=True ("Sponza-scale glTF": the same mesh as a glTF import would deliver it): every vertex carries TexCoord0 and a tangent, every
+    one of the 24 materials a base-colour (sRGB), a normal and a metallic-roughness texture of texture_size^2 RGBA8 texels; the strips
+    masked_strips (3 of 24: 11.9 % of the triangles) are AlphaMode Mask with a lattice in its base-colour alpha: not FLAG_OPAQUE in the
+    bottom level, so every candidate hit on it runs the alpha test inside the traversal (RaytracingHelpers.hlsli:19-44)."""
     rng = np.random.default_rng(seed)
+    trng = np.random.default_rng(seed + 17)                  # textures draw from their own stream: the geometry is that of the untextured scene
     strips = n_materials
     rows_per = max(1, n_side // strips)
     meshes = []
@@ -521,14 +555,26 @@ def sponza_scale(n_side=354, seed=1234, aspect=16 / 9, n_materials=24):
         idx = np.stack([i0, i0 + nc, i0 + 1, i0 + 1, i0 + nc, i0 + nc + 1], -1).reshape(-1)
         col = tuple(0.25 + 0.6 * rng.random(3))
         mat = material(col, metallic=float(s % 5 == 0), roughness=float(0.08 + 0.8 * rng.random()))
-        meshes.append(Mesh(make_vertices(pos, nrm), make_indices(idx), True, mat))
+        if not textured:
+            meshes.append(Mesh(make_vertices(pos, nrm), make_indices(idx), True, mat))
+        else:
+            masked = s in masked_strips
+            tex = _material_textures(trng, texture_size, masked)
+            mat = material((1.0, 1.0, 1.0), metallic=1.0, roughness=1.0)     # glTF factors of 1: the textures carry the values
+            if masked:
+                mat["AlphaMode"] = 1; mat["AlphaCutoff"] = 0.5
+            uv = np.stack([px * 1.5, pz * 1.5], -1).reshape(-1, 2)
+            tan = np.stack([np.ones_like(dy_dx), dy_dx, np.zeros_like(dy_dx)], -1).reshape(-1, 3)
+            tan /= np.linalg.norm(tan, axis=1, keepdims=True)
+            meshes.append(Mesh(make_vertices(pos, nrm, uv, tan), make_indices(idx), True, mat, has_tangents=True, has_uv=(True, False),
+                               textures={"BaseColor": (tex[0], 0), "Normal": (tex[1], 0), "MetallicRoughness": (tex[2], 0)}))
         r0 = r1
     light = quad_mesh((-1.5, 0, -1.5), (1.5, 0, -1.5), (1.5, 0, 1.5), (-1.5, 0, 1.5), (0, -1, 0),
                       material((0.8, 0.8, 0.8), emissive=(1, 0.95, 0.9), strength=20.0))
     nodes = [MeshNode(meshes), MeshNode([light])]
     objects = [RenderObject(0, trs()), RenderObject(1, trs((0, 3.0, 4.0)))]
     cam = make_camera((0, 0.4, -0.5), forward=(0, -0.12, 1), hfov_deg=90.0, aspect=aspect)
-    return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, -1)), name="sponza_scale").finalize()
+    return Scene(nodes, objects, cam, make_scene_data((0, 0, 0, -1)), name="sponza_scale_textured" if textured else "sponza_scale").finalize()
 
 
 def instanced_grid(n=100, seed=42, aspect=16 / 9, subdiv=2):

@@ -131,6 +131,35 @@ def test_c3_sponza_scale_250k_triangles_1080p(gpu, ptamd, oracle, pkg):
     g.close()
 
 
+def test_c3_textured_alpha_tested_1080p(gpu, ptamd, oracle, pkg):
+    """Rows f2 / a9 at the scale of BASELINE configs[2] ("Sponza-scale glTF"): the C3 mesh as a glTF import delivers it -- TexCoord0 and
+    tangents on every vertex, 24 materials with base-colour (sRGB), normal and metallic-roughness textures of 1024 x 1024 RGBA8 texels
+    each (288 MB of texels), three strips (11.9 % of the triangles) alpha-masked, i.e. not FLAG_OPAQUE: their candidates run the alpha
+    test inside the traversal. This is the workload `bench.py --workload c3t` times. One band under the sky (tolerance: powf), one
+    through a masked strip under a constant environment (bit for bit), both against the oracle's own BVH."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 1920, 1080
+    scene = S.sponza_scale(aspect=W / H, textured=True)
+    assert scene.triangle_count == 250634 and len(scene.heap) == 2 * 25 + 3 * 24
+    assert int((scene.object_data["Material"]["AlphaMode"] == 1).sum()) == 3
+    gs = S.graphics_settings(W, H, spp=1, bounces=8)
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=24, band_index=27, exact=False)
+    scene.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    full, cf = full_and_band(ptamd, gpu, oracle, L, scene, gs, W, H, band=24, band_index=34, exact=True)
+    # the masked strips are really see-through: the same frame with their alpha mode set to Opaque differs
+    opaque = S.sponza_scale(aspect=W / H, textured=True, texture_size=64)
+    opaque.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    masked = S.sponza_scale(aspect=W / H, textured=True, texture_size=64)
+    masked.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    for m in opaque.nodes[0].meshes:
+        m.material["AlphaMode"] = 0
+    opaque.finalize()
+    a, _ = gpu_render(ptamd, gpu, masked, gs, W, H)
+    b, _ = gpu_render(ptamd, gpu, opaque, gs, W, H)
+    holes = np.isfinite(b["Position"][..., 3]) & (a["Position"][..., 2] != b["Position"][..., 2])
+    assert holes.sum() > 1000                                # primary rays that pass through a cut-out cell of the lattice
+
+
 def test_c5_ten_thousand_instances_1080p(gpu, ptamd, oracle, pkg):
     S, L = pkg.scenes, pkg.layouts
     W, H = 1920, 1080
