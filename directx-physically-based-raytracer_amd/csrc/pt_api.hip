@@ -79,7 +79,8 @@ void pt_destroy(PtContext* ctx)
         v->sceneOwner = nullptr; v->tlas = Tlas(); v->blobDev = nullptr; v->blobCapacity = 0; v->blob = BlobView{}; v->haveTlas = false;
         v->blasTableDev = nullptr; v->instSourceDev = nullptr; v->blasTableCount = 0; v->normalsShared = false;
         v->objects = nullptr; v->objectCount = 0; v->instanceData = nullptr; v->instanceDataCount = 0;
-        if (v->graphExec) { hipGraphExecDestroy(v->graphExec); v->graphExec = nullptr; v->graphKey.clear(); }
+        if (v->graphExec) { hipGraphExecDestroy(v->graphExec); v->graphExec = nullptr; }
+        v->graphKey.clear(); v->chainGraphKey.clear();
     }
     c.viewers.clear(); c.borrowers = 0;
     for (auto& kv : c.blas) free_blas(kv.second);
@@ -95,6 +96,10 @@ void pt_destroy(PtContext* ctx)
     if (c.tlasHeaderEvent) hipEventDestroy(c.tlasHeaderEvent);
     if (c.validateDev) hipFree(c.validateDev);
     if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
+    if (c.shadeTexDev) hipFree(c.shadeTexDev);
+    for (hipStream_t st : c.chainStream) if (st) hipStreamDestroy(st);
+    if (c.chainFork) hipEventDestroy(c.chainFork);
+    for (hipEvent_t ev : c.chainJoin) if (ev) hipEventDestroy(ev);
     if (c.shadeRecA) hipFree(c.shadeRecA);
     if (c.shadeRecB) hipFree(c.shadeRecB);
     for (int k = 0; k < 2; k++) {
@@ -103,6 +108,7 @@ void pt_destroy(PtContext* ctx)
         for (void* p : ptrs) if (p) hipFree(p);
     }
     if (c.graphExec) hipGraphExecDestroy(c.graphExec);
+    for (hipGraphExec_t ge : c.chainGraph) if (ge) hipGraphExecDestroy(ge);
     if (c.frameConstants) hipFree(c.frameConstants);
     if (c.primaryRecords) hipFree(c.primaryRecords);
     if (c.pixelAux) hipFree(c.pixelAux);
@@ -129,7 +135,16 @@ int pt_set_frames_in_flight(PtContext* ctx, uint32_t frames)
     if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
     API_ARG(&ctx->c, frames >= 1, "frames in flight must be at least 1");
     ctx->c.framesInFlight = frames;
-    ctx->c.graphKey.clear();                              // the launch geometry of the captured frame depends on it
+    ctx->c.graphKey.clear(); ctx->c.chainGraphKey.clear();   // the launch geometry of the captured frame depends on it
+    return PT_OK;
+}
+
+int pt_set_round_chains(PtContext* ctx, uint32_t chains)
+{
+    if (!ctx) return PT_ERROR_INVALID_ARGUMENT;
+    API_ARG(&ctx->c, chains <= Context::kMaxChains, "at most 4 chains");
+    ctx->c.chains = chains;
+    ctx->c.graphKey.clear(); ctx->c.chainGraphKey.clear();
     return PT_OK;
 }
 
@@ -613,12 +628,14 @@ static int validate_scene(Context& c)
         if (c.objectCount > c.shadeGeomCap) {                // the resolved-geometry table the same kernel fills (grow-only; kernels in flight may read the old one)
             API_HIP(&c, hipStreamSynchronize(c.stream));
             if (c.shadeGeomDev) hipFree(c.shadeGeomDev);
-            c.shadeGeomDev = nullptr; c.shadeGeomCap = 0;
+            if (c.shadeTexDev) hipFree(c.shadeTexDev);
+            c.shadeGeomDev = nullptr; c.shadeTexDev = nullptr; c.shadeGeomCap = 0;
+            API_HIP(&c, hipMalloc((void**)&c.shadeTexDev, sizeof(HeapEntry) * kTextureSlots * (size_t)c.objectCount));
             API_HIP(&c, hipMalloc((void**)&c.shadeGeomDev, sizeof(ShadeGeom) * c.objectCount));
             c.shadeGeomCap = c.objectCount;
         }
         API_HIP(&c, hipMemsetAsync(c.validateDev, 0, sizeof(uint32_t) * 8, c.stream));
-        API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev, c.shadeGeomDev));
+        API_HIP(&c, launch_validate_objects(c.stream, c.objects, c.objectCount, c.heapDev, heapCount, c.validateDev, c.shadeGeomDev, c.shadeTexDev));
         // do all instances of a bottom level name the same vertex data? (the frame's normal records are made from the first one's objects)
         if (c.blasTableDev && c.instSourceDev)
             API_HIP(&c, launch_check_shared_geometry(c.stream, c.instSourceDev, c.blasTableDev, c.blob.instCount, c.shadeGeomDev, c.validateDev));
@@ -659,7 +676,7 @@ static int make_views(Context& c, uint32_t width, uint32_t height, SceneView& sv
                 "SceneData.EnvironmentLightTextureDescriptor is not the kind of texture IsEnvironmentLightTextureCubeMap says");
     }
     sv.accel.instances = c.tlas.instances; sv.accel.instanceCount = c.tlas.instanceCount;
-    sv.objects = c.objects; sv.objectCount = c.objectCount; sv.shadeGeom = c.shadeGeomDev;
+    sv.objects = c.objects; sv.objectCount = c.objectCount; sv.shadeGeom = c.shadeGeomDev; sv.shadeTex = c.shadeTexDev;
     sv.instanceData = c.instanceData;
     sv.heap = c.heapDev; sv.heapCount = (uint32_t)c.heapHost.size();
     sv.srgbLut = c.srgbLutDev;

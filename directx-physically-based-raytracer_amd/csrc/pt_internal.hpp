@@ -62,7 +62,8 @@ struct BlobCopy { const void* src; void* dst; uint64_t n16; };
 
 // What hit reconstruction needs of an object's geometry, resolved once per change of (ObjectData, heap) by the validation kernel: the
 // object record -> descriptor table -> buffer chain of the reference (RaytracingHelpers.hlsli:82-85) is one fetch here.
-struct alignas(16) ShadeGeom { const uint8_t* vb; const void* ib; uint32_t stride, ibStride, nOff, tOff; };   // nOff / tOff = ~0u: attribute absent
+struct alignas(16) ShadeGeom { const uint8_t* vb; uint32_t stride, nOff, tOff, uvOff[2], _pad; };   // offsets of normal / tangent / the two texture-coordinate sets inside a vertex; ~0u: attribute absent.
+                                                                                                 // (a triangle's vertex indices come from the traversal copy, not from the object's index buffer)
 static_assert(sizeof(ShadeGeom) == 32, "layout");
 
 // everything a render kernel needs about the scene, passed by value as a kernel argument
@@ -70,6 +71,7 @@ struct SceneView {
     AccelView accel;
     const PtObjectData* objects;
     const ShadeGeom* shadeGeom;              // [objectCount]
+    const HeapEntry* shadeTex;               // [objectCount * 7]: the objects' resolved texture slots (pt_texture.hpp TextureSlots)
     const PtInstanceData* instanceData;
     const HeapEntry* heap;
     const float* srgbLut;                    // 256-entry sRGB -> linear table (device)
@@ -138,6 +140,7 @@ struct Context {
     uint64_t tlasObjectEnd = 0;                       // max over instances of InstanceID + geometry count: ObjectData must reach that far
     uint32_t sqShift = kSubQueueShiftFused;   // log2 of the number of sub-queues of the frame being enqueued (launch_raytrace)
     ShadeGeom* shadeGeomDev = nullptr; uint32_t shadeGeomCap = 0;
+    HeapEntry* shadeTexDev = nullptr;                 // same capacity: 7 resolved texture slots per object
     // per-frame copy of the vertex normals, one record per triangle packet of the traversal copy (pt_shade.hpp ShadeTables)
     uint4* shadeRecA = nullptr; uint32_t* shadeRecB = nullptr; uint32_t shadeRecCap = 0;
     const BlasEntry* blasTableDev = nullptr; uint32_t blasTableCount = 0; uint32_t blasTableMaxTris = 0;    // the top-level build's table of bottom levels (device; a viewer: the owner's)
@@ -160,6 +163,12 @@ struct Context {
     float2* pixelAux = nullptr; uint32_t pixelAuxCapacity = 0;   // denoiser modes: first-bounce hit distance | isDiffuse per pixel
     FrameConstants* frameConstants = nullptr;
     hipGraphExec_t graphExec = nullptr; std::string graphKey; bool disableGraphs = false;
+    // chains of a frame (pt_kernels.hip launch_raytrace): the rounds of a group of sub-queues need nothing from the other groups, so each group's
+    // chain of launches is a linear graph replayed on a stream of its own, behind the frame's preamble and joined to the context's stream.
+    static constexpr uint32_t kMaxChains = 4;
+    uint32_t chains = 0;                              // 0: the library chooses (pt_set_round_chains)
+    hipStream_t chainStream[kMaxChains - 1] = { nullptr, nullptr, nullptr }; hipEvent_t chainFork = nullptr, chainJoin[kMaxChains - 1] = { nullptr, nullptr, nullptr };
+    hipGraphExec_t chainGraph[kMaxChains] = { nullptr, nullptr, nullptr, nullptr }; std::string chainGraphKey;
     uint32_t* queueCounts = nullptr; uint32_t queueCountsCap = 0;
     struct RoundArgs* roundArgs = nullptr; uint32_t roundArgsCap = 0; std::string roundArgsKey;   // per-round argument blocks of k_round (device)
     DeviceCounters* counters = nullptr;
@@ -190,9 +199,9 @@ hipError_t launch_skin(hipStream_t stream, const void* skeletal, const float* tr
 
 // pt_stream.hip
 hipError_t launch_shade(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, const PathQueue& qin, const PathQueue& qout, float2* aux,
-                        uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid);
+                        uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid, hipStream_t stream, uint32_t sqBase, uint32_t sqCount);
 hipError_t launch_extend_stream(Context& c, const AlphaContext& ac, const PathQueue& q, uint32_t segCap, const uint32_t* count, uint32_t* cursor,
-                                uint32_t grid, bool stats, bool writeT);
+                                uint32_t grid, bool stats, bool writeT, hipStream_t stream, uint32_t sqBase, uint32_t sqCount);
 
 // pt_kernels.hip
 hipError_t launch_gbuffer(Context& c, const SceneView& sv, const FrameView& fv, uint32_t flags, const PtTextures& tx);
@@ -204,7 +213,7 @@ uint32_t round_objects_in_lds(const Context& c, uint32_t objectCount, bool haveS
 uint32_t round_records_in_lds(const Context& c, uint32_t objectCount, bool haveShadeGeom);
 inline bool normal_records_usable(const Context& c) { return c.normalsShared && c.blasTableDev && c.blasTableCount <= 65535u /* grid.y of k_capture_normals */ && c.shadeRecA && c.blob.triCount && c.blob.triCount <= c.shadeRecCap; }
 hipError_t launch_check_shared_geometry(hipStream_t stream, const InstanceSource* src, const BlasEntry* table, uint32_t n, const ShadeGeom* shadeGeom, uint32_t* out);
-hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom);
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom, HeapEntry* shadeTex);
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,
                                uint32_t bandHeight, uint32_t width, uint32_t height, uint32_t pixelBytes);
 

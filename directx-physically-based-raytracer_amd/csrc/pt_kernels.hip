@@ -363,7 +363,7 @@ struct RoundArgs {
 };
 
 template <bool TEXTURED, bool LDS, bool FLAT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(const RoundArgs* __restrict__ A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_round(const RoundArgs* __restrict__ A, uint32_t sqBase, uint32_t sqCount)
 {
     const SceneView& sv = A->sv; const FrameView& fv = A->fv; const PtTextures& tx = A->tx; const BlobView& bv = A->bv;
     const PathQueue& qin = A->qin; const PathQueue& qout = A->qout;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr uint32_t kFixed = FLAT ? kFlatLdsFixed : kExtendLdsFixed;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
     const uint32_t sqShift = A->sqShift;
-    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
+    const uint32_t nsq = 1u << sqShift, bq = blockIdx.x / sqCount, sq = sqBase + (blockIdx.x - bq * sqCount), nbq = gridDim.x / sqCount;   // this launch serves sub-queues [sqBase, sqBase + sqCount): one chain of the frame
     const uint32_t nT = countIn[sq], nF = countIn[nsq + sq];
     const uint32_t seg = sq * segCap;
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         } else {
             blob.p = bv.base;
         }
-        AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+        AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
         TraceStats st; st.nodes = 0; st.tris = 0; st.overflow = 0;
         for (uint32_t base = bq * 256u; base < nT; base += nbq * 256u) {
             const uint32_t local = base + threadIdx.x;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_debug_trace(BlobView bv, AlphaContext a
 
 hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8, uint32_t* devLog, uint32_t logCap)
 {
-    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
     k_debug_trace<<<1, 256, 0, c.stream>>>(c.blob, ac, make_float4(ray8[0], ray8[1], ray8[2], ray8[3]), make_float4(ray8[4], ray8[5], ray8[6], ray8[7]), devLog, logCap);
     return hipGetLastError();
 }
@@ -536,7 +536,7 @@ hipError_t launch_debug_trace(Context& c, const SceneView& sv, const float* ray8
 // scene-input validation (pt_api.hip validate_scene): every descriptor index ObjectData carries must name a heap entry of the
 // right kind. out: error member (1 Vertices, 2 Indices, 3 MotionVectors, 4 TextureMapInfo) | object | descriptor | 1 = wrong kind
 __global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uint32_t count, const HeapEntry* __restrict__ heap, uint32_t heapCount, uint32_t* out,
-                                   ShadeGeom* __restrict__ shadeGeom)
+                                   ShadeGeom* __restrict__ shadeGeom, HeapEntry* __restrict__ shadeTex)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -554,19 +554,26 @@ __global__ void k_validate_objects(const PtObjectData* __restrict__ objects, uin
         if (d >= heapCount) { err = 4; desc = d; }
         else if (heap[d].kind != kKindTexture2D) { err = 4; desc = d; kind = 1; }
     }
+    for (uint32_t k = 0; k < kTextureSlots; k++) {         // the resolved texture slots (pt_texture.hpp TextureSlots): a copy of the heap entry, the coordinate set in `kind`
+        HeapEntry e; e.ptr = nullptr; e.bytes = 0; e.stride = 0; e.kind = 0;
+        const uint32_t d = od->TextureMapInfoArray[k].Descriptor;
+        if (!err && d != ~0u) { e = heap[d]; e.kind = od->TextureMapInfoArray[k].TextureCoordinateIndex & 1u; }
+        shadeTex[(size_t)i * kTextureSlots + k] = e;
+    }
     if (err && atomicCAS(&out[0], 0u, err) == 0u) { out[1] = i; out[2] = desc; out[3] = kind; }
     // the resolved geometry of the object (ShadeGeom): an object without vertex / index buffers has no vertex attributes to fetch
-    ShadeGeom sg; sg.vb = nullptr; sg.ib = nullptr; sg.stride = 0; sg.ibStride = 0; sg.nOff = ~0u; sg.tOff = ~0u;
+    ShadeGeom sg; sg.vb = nullptr; sg.stride = 0; sg.nOff = ~0u; sg.tOff = ~0u; sg.uvOff[0] = sg.uvOff[1] = ~0u; sg._pad = 0;
     if (!err && md[0] != ~0u && md[1] != ~0u) {
-        sg.vb = (const uint8_t*)heap[md[0]].ptr; sg.ib = heap[md[1]].ptr; sg.stride = od->VertexDesc.Stride; sg.ibStride = heap[md[1]].stride;
+        sg.vb = (const uint8_t*)heap[md[0]].ptr; sg.stride = od->VertexDesc.Stride;
         sg.nOff = od->VertexDesc.AttributeOffsets.Normal; sg.tOff = od->VertexDesc.AttributeOffsets.Tangent;
+        sg.uvOff[0] = od->VertexDesc.AttributeOffsets.TextureCoordinates[0]; sg.uvOff[1] = od->VertexDesc.AttributeOffsets.TextureCoordinates[1];
     }
     shadeGeom[i] = sg;
 }
 
-hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom)
+hipError_t launch_validate_objects(hipStream_t stream, const PtObjectData* objects, uint32_t count, const HeapEntry* heap, uint32_t heapCount, uint32_t* out, ShadeGeom* shadeGeom, HeapEntry* shadeTex)
 {
-    if (count) k_validate_objects<<<(count + 255) / 256, 256, 0, stream>>>(objects, count, heap, heapCount, out, shadeGeom);
+    if (count) k_validate_objects<<<(count + 255) / 256, 256, 0, stream>>>(objects, count, heap, heapCount, out, shadeGeom, shadeTex);
     return hipGetLastError();
 }
 
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(256) void k_bsdf_evaluate(const float* __restrict__
 hipError_t launch_visibility(Context& c, const SceneView& sv, const void* rays, uint32_t count, void* out)
 {
     if (!count) return hipSuccess;
-    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
     k_visibility<<<persistent_grid(c), 256, 0, c.stream>>>(c.blob, ac, (const float4*)rays, count, (float4*)out, c.counters);
     return hipGetLastError();
 }
@@ -749,71 +756,106 @@ uint32_t round_records_in_lds(const Context& c, uint32_t objectCount, bool haveS
 }
 static uint32_t round_records_in_lds(const Context& c, const SceneView& sv) { return round_records_in_lds(c, sv.objectCount, sv.shadeGeom != nullptr); }
 
-// the launch sequence of one frame after k_set_constants (which also zeroes the queue counters): k_pt_init, then the rounds
-static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
+// ---- the launch sequence of one frame after k_set_constants (which also zeroes the queue counters) ----------------------------------
+// preamble: the frame's normal records and k_pt_first (= k_pt_init + round 0), on the context's stream;
+// then the rounds -- as `chains` independent chains of launches, one per group of sub-queues. A path never leaves its sub-queue, so from
+// k_pt_first on the groups need nothing from each other: chain g takes sub-queues [sqBase, sqBase + sqCount) through all the rounds.
+// chains > 1 (launch_raytrace): every chain is a linear hipGraph of its own, replayed on a stream of its own behind an event recorded after the
+// preamble, and the context's stream waits for all of them -- the tail of one chain's launch (a few long walks, a few blocks) overlaps the other
+// chains' launches. That is what several frames in flight do BETWEEN frames, done inside ONE frame: what a renderer that presents one frame at a
+// time needs (the reference: Source/App.cpp:167). (Parallel branches inside one captured graph -- fork / join events during capture -- were the
+// first form: on ROCm 7.2 their kernels ran without waiting for the fork point and faulted; plain streams and events are what frames in flight
+// have always used here.)
+#ifndef PT_AB_CHAINS
+#define PT_AB_CHAINS 3
+#endif
+struct FrameForm { bool streaming, fused, first; };
+static FrameForm frame_form(const Context& c)
+{
+    const uint32_t lockStepFlags = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+    const uint32_t pairOnlyFlags = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
+    FrameForm f;
+    f.streaming = c.blob.bytes > kBlobLdsMax && !(c.debugFlags & lockStepFlags);   // a scene that does not fit LDS: persistent traversal lanes with ray replacement
+    f.fused = !f.streaming && !(c.debugFlags & pairOnlyFlags);                     // fused rounds: everything except the validation / statistics variants
+    f.first = f.streaming || f.fused;                                              // the product paths start with k_pt_first; the validation variants keep k_pt_init and round 0 apart
+    return f;
+}
+static uint32_t frame_chains(const Context& c, bool ownStreams)
+{
+    // on streams of their own: the library's choice unless the caller made one; direct launches (per-launch events, the default stream): only
+    // what the caller asked for, one chain after the other on the context's stream
+    const uint32_t want = c.chains ? c.chains : (ownStreams ? (uint32_t)PT_AB_CHAINS : 1u);
+    return std::max(1u, std::min({ want, Context::kMaxChains, 1u << c.sqShift }));
+}
+
+static hipError_t enqueue_preamble(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t segCap, uint32_t grid)
 {
     const uint32_t nsq = 1u << c.sqShift, cstride = 3u * nsq;                  // traced + fresh counters + the streaming form's cursor, per round
     float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
     if (normal_records_usable(c))                          // the frame's normal records, from the vertex buffers as they are now
         k_capture_normals<<<dim3(std::min((c.blasTableMaxTris + 255u) / 256u, 64u), c.blasTableCount), 256, 0, c.stream>>>(c.blasTableDev, sv.shadeGeom, c.shadeRecA, c.shadeRecB);
-    // the product paths start with k_pt_first (k_pt_init + round 0); the validation / statistics variants keep the two apart
-    const uint32_t lockStepFlags = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
-    const uint32_t pairOnlyFlags = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
-    const bool streamingForm = c.blob.bytes > kBlobLdsMax && !(c.debugFlags & lockStepFlags), fusedForm = !streamingForm && !(c.debugFlags & pairOnlyFlags);
-    const bool first = streamingForm || fusedForm;
-    if (first) k_pt_first<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[1], aux, segCap, &c.queueCounts[cstride], c.primaryRecords, c.sqShift);
+    if (frame_form(c).first) k_pt_first<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[1], aux, segCap, &c.queueCounts[cstride], c.primaryRecords, c.sqShift);
     else k_pt_init<<<grid, 256, 0, c.stream>>>(fv, c.frameConstants, tx, c.queue[0], aux, segCap, &c.queueCounts[nsq], c.primaryRecords, c.sqShift);
+    return hipGetLastError();
+}
+
+// chain g of `chains`: the rounds of its sub-queues, on stream s (product forms only: frame_form(c).first)
+static hipError_t enqueue_chain(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid,
+                                uint32_t g, uint32_t chains, hipStream_t s)
+{
+    const uint32_t nsq = 1u << c.sqShift, cstride = 3u * nsq;
+    float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
+    const FrameForm form = frame_form(c);
     const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
-    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
-    {
-        const bool lds = c.blob.bytes <= kBlobLdsMax;
-        const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
-        const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u) + round_objects_in_lds(c, sv) * kObjLds16 * 16u + lds_bytes_of_records(round_records_in_lds(c, sv));
-        // a scene that does not fit LDS: the streaming form (persistent traversal lanes with ray replacement)
-        const uint32_t lockStep = PT_DEBUG_LOCKSTEP | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
-        if (!lds && !(c.debugFlags & lockStep)) {
-            const bool wt = aux != nullptr;
-            for (uint32_t r = 0; r <= rounds; r++) {
-                PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
-                uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
-                if (r > 0) {                                                // (round 0's shading half ran inside k_pt_first)
-                    timing_begin(c, c.evShade, c.nShade);
-                    launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, grid);
-                    timing_end(c, c.evShade, c.nShade); c.nShade++;
-                }
-                if (r == rounds) break;
-                timing_begin(c, c.evExtend, c.nExtend);
-                // Fewer, longer-lived waves than the other kernels: a wave only keeps its lanes busy if it refills them many times, and with
-                // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
-                // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
-                // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-                launch_extend_stream(c, ac, qout, segCap, cout, cout + 2u * nsq, grid, stats, wt);
-                timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
+    const uint32_t perSq = std::max(1u, grid / nsq);                           // blocks per sub-queue
+    const uint32_t sqBase = (uint32_t)((uint64_t)nsq * g / chains), sqCount = (uint32_t)((uint64_t)nsq * (g + 1) / chains) - sqBase;
+    if (form.streaming) {                                                      // round 0's shading half ran inside k_pt_first
+        const bool wt = aux != nullptr;
+        for (uint32_t r = 0; r <= rounds; r++) {
+            PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
+            uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
+            if (r > 0) {
+                timing_begin(c, c.evShade, c.nShade);
+                launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, perSq * sqCount, s, sqBase, sqCount);
+                timing_end(c, c.evShade, c.nShade); c.nShade++;
             }
-            return hipGetLastError();
+            if (r == rounds) break;
+            timing_begin(c, c.evExtend, c.nExtend);
+            launch_extend_stream(c, ac, qout, segCap, cout, cout + 2u * nsq, grid, stats, wt, s, sqBase, sqCount);
+            timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
         }
-        // fused rounds: everything except the validation / statistics variants, which keep the two-kernel form
-        const uint32_t pairOnly = PT_DEBUG_TRAVERSAL_STATS | PT_DEBUG_BRUTE_FORCE | PT_DEBUG_TRAVERSAL_V1 | PT_DEBUG_UNFUSED_ROUNDS;
-        if (!(c.debugFlags & pairOnly)) {
-            for (uint32_t r = 1; r <= rounds; r++) {                        // queues and counters of round r: in its argument block (launch_raytrace); round 0 ran inside k_pt_first
-                timing_begin(c, c.evRound, c.nRound);
-                #define PT_ROUND(T, L, F) k_round<T, L, F><<<grid, 256, smem, c.stream>>>(c.roundArgs + r)
-                #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)
-                #define PT_ROUND_L(T) do { if (lds) PT_ROUND_F(T, true); else PT_ROUND_F(T, false); } while (0)
-                if (c.heapHasTextures) PT_ROUND_L(true); else PT_ROUND_L(false);
-                #undef PT_ROUND_L
-                #undef PT_ROUND_F
-                #undef PT_ROUND
-                timing_end(c, c.evRound, c.nRound); c.nRound++;
-            }
-            return hipGetLastError();
-        }
+        return hipGetLastError();
     }
+    const bool lds = c.blob.bytes <= kBlobLdsMax;
+    const bool flat = c.blob.instCount <= kFlatInstances && !(c.debugFlags & PT_DEBUG_TRAVERSAL_PHASED);
+    const uint32_t smem = (flat ? kFlatLdsFixed : kExtendLdsFixed) + (lds ? c.blob.bytes : 0u) + round_objects_in_lds(c, sv) * kObjLds16 * 16u + lds_bytes_of_records(round_records_in_lds(c, sv));
+    for (uint32_t r = 1; r <= rounds; r++) {                        // queues and counters of round r: in its argument block (launch_raytrace); round 0 ran inside k_pt_first
+        timing_begin(c, c.evRound, c.nRound);
+        #define PT_ROUND(T, L, F) k_round<T, L, F><<<perSq * sqCount, 256, smem, s>>>(c.roundArgs + r, sqBase, sqCount)
+        #define PT_ROUND_F(T, L) do { if (flat) PT_ROUND(T, L, true); else PT_ROUND(T, L, false); } while (0)
+        #define PT_ROUND_L(T) do { if (lds) PT_ROUND_F(T, true); else PT_ROUND_F(T, false); } while (0)
+        if (c.heapHasTextures) PT_ROUND_L(true); else PT_ROUND_L(false);
+        #undef PT_ROUND_L
+        #undef PT_ROUND_F
+        #undef PT_ROUND
+        timing_end(c, c.evRound, c.nRound); c.nRound++;
+    }
+    return hipGetLastError();
+}
+
+// the validation / statistics variants: two kernels per round over all sub-queues, on the context's stream
+static hipError_t enqueue_validation_rounds(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid)
+{
+    const uint32_t nsq = 1u << c.sqShift, cstride = 3u * nsq;
+    float2* aux = c.settings.Denoiser != PT_DENOISER_NONE ? c.pixelAux : nullptr;
+    const bool stats = (c.debugFlags & PT_DEBUG_TRAVERSAL_STATS) != 0;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
     for (uint32_t r = 0; r <= rounds; r++) {
         PathQueue& qin = c.queue[r & 1]; PathQueue& qout = c.queue[(r + 1) & 1];
         uint32_t* cin = &c.queueCounts[r * cstride]; uint32_t* cout = &c.queueCounts[(r + 1) * cstride];
         timing_begin(c, c.evShade, c.nShade);
-        launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, grid);
+        launch_shade(c, sv, fv, tx, qin, qout, aux, segCap, cin, cout, grid, c.stream, 0u, nsq);
         timing_end(c, c.evShade, c.nShade); c.nShade++;
         if (r == rounds) break;
         timing_begin(c, c.evExtend, c.nExtend);
@@ -839,6 +881,16 @@ static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView
         timing_end(c, c.evExtend, c.nExtend); c.nExtend++;
     }
     return hipGetLastError();
+}
+
+// the whole frame on the context's stream: preamble, then the chains one after the other (or the validation rounds)
+static hipError_t enqueue_frame(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, uint32_t rounds, uint32_t segCap, uint32_t grid, uint32_t chains)
+{
+    hipError_t e = enqueue_preamble(c, sv, fv, tx, segCap, grid);
+    if (e != hipSuccess) return e;
+    if (!frame_form(c).first) return enqueue_validation_rounds(c, sv, fv, tx, rounds, segCap, grid);
+    for (uint32_t g = 0; g < chains && e == hipSuccess; g++) e = enqueue_chain(c, sv, fv, tx, rounds, segCap, grid, g, chains, c.stream);
+    return e;
 }
 
 template <typename T> static void key_add(std::string& k, const T& v) { k.append((const char*)&v, sizeof v); }
@@ -887,7 +939,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     key_add(key, sv); key_add(key, fv); key_add(key, tx); key_add(key, rounds); key_add(key, segCap); key_add(key, grid);
     key_add(key, c.queue[0]); key_add(key, c.queue[1]); key_add(key, c.queueCounts); key_add(key, c.blob); key_add(key, c.heapHasTextures);
     key_add(key, c.frameConstants); key_add(key, c.primaryRecords); key_add(key, c.stream); key_add(key, c.pixelAux); key_add(key, gs.Denoiser); key_add(key, c.debugFlags);
-    key_add(key, c.framesInFlight); key_add(key, c.sqShift);
+    key_add(key, c.framesInFlight); key_add(key, c.sqShift); key_add(key, c.chains);
     key_add(key, c.shadeRecA); key_add(key, c.blasTableDev); key_add(key, c.blasTableCount); key_add(key, c.blasTableMaxTris); key_add(key, normal_records_usable(c));
     if (key != c.roundArgsKey || !c.roundArgs) {                              // k_round's argument blocks, one per round (device memory)
         if (rounds + 1 > c.roundArgsCap) {
@@ -914,25 +966,58 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     // hipGraph replay: launch-bound frames (small shards, tail rounds) cost ~75 launches; a replay is one submission.
     const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
                            (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP | PT_DEBUG_GATHER_LOCAL_ONLY | PT_DEBUG_GATHER_SELF_EXCHANGE)) == 0;   // counters / validation variants launch directly
-    if (graphable) {
-        if (key != c.graphKey || !c.graphExec) {
-            if (c.graphExec) { hipGraphExecDestroy(c.graphExec); c.graphExec = nullptr; }
-            c.graphKey.clear();
-            hipGraph_t graph = nullptr;
-            e = hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed);
-            if (e == hipSuccess) {
-                hipError_t e2 = enqueue_frame(c, sv, fv, tx, rounds, segCap, grid);
-                e = hipStreamEndCapture(c.stream, &graph);
-                if (e == hipSuccess) e = e2;
+    auto capture = [&](hipStream_t s, hipGraphExec_t& exec, auto&& body) -> hipError_t {          // one linear graph from what `body` enqueues on s
+        if (exec) { hipGraphExecDestroy(exec); exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+        if (ce == hipSuccess) {
+            const hipError_t e2 = body();
+            ce = hipStreamEndCapture(s, &graph);
+            if (ce == hipSuccess) ce = e2;
+        }
+        if (ce == hipSuccess) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) hipGraphDestroy(graph);
+        if (ce != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+        return ce;
+    };
+    const uint32_t chains = frame_form(c).first ? frame_chains(c, graphable) : 1u;
+    if (graphable && chains > 1) {
+        // every chain a linear graph on a stream of its own; the preamble is launched directly (two kernels)
+        if (!c.chainFork && (e = hipEventCreateWithFlags(&c.chainFork, hipEventDisableTiming)) != hipSuccess) return e;
+        for (uint32_t g = 1; g < chains; g++) {
+            if (!c.chainStream[g - 1] && (e = hipStreamCreateWithFlags(&c.chainStream[g - 1], hipStreamNonBlocking)) != hipSuccess) return e;
+            if (!c.chainJoin[g - 1] && (e = hipEventCreateWithFlags(&c.chainJoin[g - 1], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if (key != c.chainGraphKey) {
+            c.chainGraphKey.clear();
+            for (uint32_t g = 0; g < chains; g++) {
+                hipStream_t s = g == 0 ? c.stream : c.chainStream[g - 1];
+                if (capture(s, c.chainGraph[g], [&] { return enqueue_chain(c, sv, fv, tx, rounds, segCap, grid, g, chains, s); }) != hipSuccess) { c.disableGraphs = true; break; }
             }
-            if (e == hipSuccess) e = hipGraphInstantiate(&c.graphExec, graph, nullptr, nullptr, 0);
-            if (graph) hipGraphDestroy(graph);
-            if (e != hipSuccess) { c.graphExec = nullptr; c.disableGraphs = true; (void)hipGetLastError(); }
+            if (!c.disableGraphs) c.chainGraphKey = key;
+        }
+        if (!c.disableGraphs) {
+            if ((e = enqueue_preamble(c, sv, fv, tx, segCap, grid)) != hipSuccess) return e;
+            if ((e = hipEventRecord(c.chainFork, c.stream)) != hipSuccess) return e;
+            for (uint32_t g = 1; g < chains; g++) {
+                hipStream_t s = c.chainStream[g - 1];
+                if ((e = hipStreamWaitEvent(s, c.chainFork, 0)) != hipSuccess) return e;
+                if ((e = hipGraphLaunch(c.chainGraph[g], s)) != hipSuccess) return e;
+                if ((e = hipEventRecord(c.chainJoin[g - 1], s)) != hipSuccess) return e;
+            }
+            if ((e = hipGraphLaunch(c.chainGraph[0], c.stream)) != hipSuccess) return e;
+            for (uint32_t g = 1; g < chains; g++) if ((e = hipStreamWaitEvent(c.stream, c.chainJoin[g - 1], 0)) != hipSuccess) return e;
+            return hipSuccess;
+        }
+    } else if (graphable) {
+        if (key != c.graphKey || !c.graphExec) {
+            c.graphKey.clear();
+            if (capture(c.stream, c.graphExec, [&] { return enqueue_frame(c, sv, fv, tx, rounds, segCap, grid, 1u); }) != hipSuccess) c.disableGraphs = true;
             else c.graphKey = key;
         }
         if (c.graphExec) return hipGraphLaunch(c.graphExec, c.stream);
     }
-    return enqueue_frame(c, sv, fv, tx, rounds, segCap, grid);
+    return enqueue_frame(c, sv, fv, tx, rounds, segCap, grid, frame_form(c).first ? frame_chains(c, false) : 1u);
 }
 
 hipError_t launch_deinterleave(hipStream_t stream, void* dst, const void* src, const uint64_t* rankOffsetsHost, uint32_t rankCount,

@@ -71,7 +71,7 @@ struct SurfaceHit {               // the part of HitInfo (Shaders/HitInfo.hlsli:
 
 PT_DEV AlphaContext alpha_context(const SceneView& sv)
 {
-    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances;
+    AlphaContext ac; ac.objects = sv.objects; ac.heap = sv.heap; ac.srgbLut = sv.srgbLut; ac.instances = sv.accel.instances; ac.shadeTex = sv.shadeTex;
     return ac;
 }
 
@@ -149,7 +149,7 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
         if (tables.recALds) { const f4v a = tables.recALds[hg.triIndex]; w0 = __float_as_uint(a.x); w1 = __float_as_uint(a.y); w2 = __float_as_uint(a.z); w3 = __float_as_uint(a.w); w4 = tables.recBLds[hg.triIndex]; }
         else { const uint4 a = tables.recA[hg.triIndex]; w0 = a.x; w1 = a.y; w2 = a.z; w3 = a.w; w4 = tables.recB[hg.triIndex]; }
     }
-    ShadeGeom sg; sg.vb = nullptr; sg.ib = nullptr; sg.stride = 0; sg.ibStride = 0; sg.nOff = ~0u; sg.tOff = ~0u;
+    ShadeGeom sg; sg.vb = nullptr; sg.stride = 0; sg.nOff = ~0u; sg.tOff = ~0u; sg.uvOff[0] = sg.uvOff[1] = ~0u; sg._pad = 0;
     if (!records || TEXTURED) {
         if (objLds) {
             const f4v a = objLds[h.ObjectIndex * kObjLds16], b = objLds[h.ObjectIndex * kObjLds16 + 1u];
@@ -192,8 +192,22 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
         const v3 t = interp3(tg[0], tg[1], tg[2], bu, bv);
         h.Tangent = normalize(V3(sop3(M[0], t.x, M[1], t.y, M[2], t.z), sop3(M[4], t.x, M[5], t.y, M[6], t.z), sop3(M[8], t.x, M[9], t.y, M[10], t.z)));
     }
-    const PtObjectData* od = &sv.objects[h.ObjectIndex];
-    get_texture_coordinates(od, sv.heap, prim, bu, bv, h.TextureCoordinates);      // :124-130
+    // GetTextureCoordinates (ShadingHelpers.hlsli:32-51, called at RaytracingHelpers.hlsli:124-130) from the resolved geometry and the
+    // triangle's indices at hand: the same three vertices, fetched in the dependency level of the tangents instead of behind
+    // object record -> two heap entries -> three index loads
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        h.TextureCoordinates.uv[i][0] = h.TextureCoordinates.uv[i][1] = 0.0f;
+        const uint32_t off = sg.uvOff[i];
+        if (off == ~0u) continue;
+        float a[3][2];
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const PT_GLOBAL_AS uint16_t* q = gptr<uint16_t>(sg.vb + (size_t)sg.stride * hg.vi[k] + off);
+            a[k][0] = f16_to_f32(q[0]); a[k][1] = f16_to_f32(q[1]);
+        }
+        for (int c = 0; c < 2; c++) h.TextureCoordinates.uv[i][c] = interp1(a[0][c], a[1][c], a[2][c], bu, bv);
+    }
 }
 
 PT_DEV v3 material_emission(const PtMaterial& m) { return V3(m.EmissiveColor) * m.EmissiveStrength; }
@@ -209,7 +223,7 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h, ObjectTab
         return m;
     }
     return evaluate_material(h.ShadingNormal, h.IsFrontFace ? h.Tangent : -h.Tangent, &sv.objects[h.ObjectIndex], sv.heap, sv.srgbLut,
-                             h.TextureCoordinates);                       // ShadingHelpers.hlsli:161-235
+                             h.TextureCoordinates, sv.shadeTex ? sv.shadeTex + (size_t)h.ObjectIndex * kTextureSlots : nullptr);   // ShadingHelpers.hlsli:161-235
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,11 +318,11 @@ PT_DEV bool scatter(const PtGraphicsSettings& gs, PathRegs& p, const SurfaceHit&
     float pdf; v3 f;
     bs.EvaluateLobe(svec, L, V, w, lobe, gs.ExtFlags, pdf, f);
     if (pdf == 0.0f || (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f)) return false;             // :336,342
-    p.thr = p.thr * V3(f.x / pdf, f.y / pdf, f.z / pdf);                                      // :346
+    { const float ipdf = 1.0f / pdf; p.thr = p.thr * V3(f.x * ipdf, f.y * ipdf, f.z * ipdf); }   // :346 (float3 / float = the vector times ONE reciprocal: arithmetic spec)
     if (gs.IsRussianRouletteEnabled && p.bounce > 3) {                                        // :348-356
         const float prob = fmaxf(p.thr.x, fmaxf(p.thr.y, p.thr.z));
         if (rng_float(p.rng) >= prob) return false;
-        p.thr = V3(p.thr.x / prob, p.thr.y / prob, p.thr.z / prob);
+        { const float iprob = 1.0f / prob; p.thr = V3(p.thr.x * iprob, p.thr.y * iprob, p.thr.z * iprob); }
     }
     if (ml_luminance(p.thr) <= gs.ThroughputThreshold) return false;                          // :361
     if (!(p.bounce < gs.Bounces)) return false;                                               // loop bound, :213

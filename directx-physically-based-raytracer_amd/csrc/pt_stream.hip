@@ -12,7 +12,8 @@ namespace pt {
 template <bool TEXTURED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_shade(SceneView sv, FrameView fv, const FrameConstants* __restrict__ fc, PtTextures tx,
                                                PathQueue qin, PathQueue qout, float2* aux, uint32_t segCap, const uint32_t* countIn, uint32_t* countOut,
-                                               const uint4* __restrict__ primary, BlobView bv, const uint4* __restrict__ recA, const uint32_t* __restrict__ recB, uint32_t sqShift)
+                                               const uint4* __restrict__ primary, BlobView bv, const uint4* __restrict__ recA, const uint32_t* __restrict__ recB, uint32_t sqShift,
+                                               uint32_t sqBase, uint32_t sqCount)
 {
     BlobReader<false> blob; blob.p = bv.base;
     ShadeTables tables; tables.recA = recA; tables.recB = recB;            // the frame's normal records (null: vertices are fetched at the hit)
@@ -73,10 +74,10 @@ constexpr bool kStreamTriPairs = true;                // two triangles of a leaf
 // the latency it buys back: without the shading half's registers the kernel holds more waves per SIMD).
 template <bool STATS, bool WRITE_T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_extend_stream(BlobView bv, AlphaContext ac, PathQueue q, uint32_t segCap,
-                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters, uint32_t sqShift)
+                                               const uint32_t* count, uint32_t* cursor, DeviceCounters* counters, uint32_t sqBase, uint32_t sqCount)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift;
+    const uint32_t bq = blockIdx.x / sqCount, sq = sqBase + (blockIdx.x - bq * sqCount);
     const uint32_t nT = count[sq];
     const uint32_t seg = sq * segCap;
     if (bq == 0 && threadIdx.x == 0) atomicAdd(&counters->secondaryRays, (unsigned long long)nT);
@@ -261,24 +262,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 
 hipError_t launch_shade(Context& c, const SceneView& sv, const FrameView& fv, const PtTextures& tx, const PathQueue& qin, const PathQueue& qout, float2* aux,
-                        uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid)
+                        uint32_t segCap, const uint32_t* countIn, uint32_t* countOut, uint32_t grid, hipStream_t stream, uint32_t sqBase, uint32_t sqCount)
 {
     const bool rec = normal_records_usable(c);
     const uint4* recA = rec ? c.shadeRecA : nullptr; const uint32_t* recB = rec ? c.shadeRecB : nullptr;
-    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift);
-    else k_shade<false><<<grid, 256, 0, c.stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift);
+    if (c.heapHasTextures) k_shade<true><<<grid, 256, 0, stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift, sqBase, sqCount);
+    else k_shade<false><<<grid, 256, 0, stream>>>(sv, fv, c.frameConstants, tx, qin, qout, aux, segCap, countIn, countOut, c.primaryRecords, c.blob, recA, recB, c.sqShift, sqBase, sqCount);
     return hipGetLastError();
 }
 
 hipError_t launch_extend_stream(Context& c, const AlphaContext& ac, const PathQueue& q, uint32_t segCap, const uint32_t* count, uint32_t* cursor,
-                                uint32_t grid, bool stats, bool writeT)
+                                uint32_t grid, bool stats, bool writeT, hipStream_t stream, uint32_t sqBase, uint32_t sqCount)
 {
     // Fewer, longer-lived waves than the other kernels: a wave only keeps its lanes busy if it refills them many times, and with
     // 8192 waves a 600 k-ray round gives each wave one batch of 64 (lane use then is mean / longest walk of the batch). Alone on
     // the GPU 1024 blocks are best (C3 1.42 -> 1.44 Grays/s); with other frames in flight on other streams, which fill the SIMD
     // slots a small grid leaves, 512 (C3 2.06 -> 2.22, C5 1.62 -> 1.89; 256: 2.02 / 1.80).
-    const uint32_t sgrid = std::max(1u << c.sqShift, std::min(grid, c.framesInFlight > 1 ? kStreamGridShared : kStreamGridAlone));
-    #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, c.stream>>>(c.blob, ac, q, segCap, count, cursor, c.counters, c.sqShift)
+    // (a chain of the frame gets its share of that grid: whole blocks per sub-queue)
+    const uint32_t nsq = 1u << c.sqShift;
+    const uint32_t whole = std::max(nsq, std::min(grid, c.framesInFlight > 1 ? kStreamGridShared : kStreamGridAlone));
+    const uint32_t sgrid = std::max(1u, whole / nsq) * sqCount;
+    #define PT_XS(S, W) k_extend_stream<S, W><<<sgrid, 256, kStreamLdsStack, stream>>>(c.blob, ac, q, segCap, count, cursor, c.counters, sqBase, sqCount)
     if (stats) { if (writeT) PT_XS(true, true); else PT_XS(true, false); } else { if (writeT) PT_XS(false, true); else PT_XS(false, false); }
     #undef PT_XS
     return hipGetLastError();

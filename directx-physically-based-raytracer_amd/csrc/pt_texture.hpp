@@ -93,6 +93,21 @@ PT_DEV f4 sample_map(const HeapEntry* heap, const float* srgbLut, const PtTextur
     return texture_sample(heap[info.Descriptor], srgbLut, c[0], c[1]);
 }
 
+// The seven texture slots of an object, resolved once per change of (ObjectData, heap) next to its geometry (k_validate_objects): slot k of
+// object o at resolved[o * 7 + k] is a copy of the heap entry TextureMapInfoArray[k].Descriptor names -- ptr == nullptr: no texture -- with
+// the texture-coordinate set in `kind`. A hit's texture taps then start one dependent load after the object index is known (resolved
+// slot -> texels) instead of two (TextureMapInfo -> heap entry -> texels). A view over either source, so that the code below exists once.
+struct TextureSlots {
+    const PtTextureMapInfo* info; const HeapEntry* heap; const HeapEntry* resolved;       // resolved != nullptr: use it
+    PT_DEV bool has(int k) const { return resolved ? resolved[k].ptr != nullptr : info[k].Descriptor != ~0u; }
+    PT_DEV f4 sample(int k, const float* srgbLut, const TexCoords& tc) const
+    {
+        if (resolved) { const HeapEntry e = resolved[k]; const float* c = tc.uv[e.kind & 1u]; return texture_sample(e, srgbLut, c[0], c[1]); }
+        return sample_map(heap, srgbLut, info[k], tc);
+    }
+};
+constexpr uint32_t kTextureSlots = 7;
+
 enum : int { TEX_BaseColor = 0, TEX_EmissiveColor, TEX_Metallic, TEX_Roughness, TEX_MetallicRoughness, TEX_Transmission, TEX_Normal };
 
 PT_DEV uint32_t load_index_tex(const void* ib, uint32_t stride, uint32_t i)
@@ -120,12 +135,12 @@ PT_DEV void get_texture_coordinates(const PtObjectData* od, const HeapEntry* hea
 }
 
 // IsOpaque (closest-hit overload), ShadingHelpers.hlsli:105-115
-PT_DEV bool is_opaque(const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc)
+PT_DEV bool is_opaque(const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc, const HeapEntry* resolved = nullptr)
 {
     float a = od->Material.BaseColor[3];
-    const PtTextureMapInfo& info = od->TextureMapInfoArray[TEX_BaseColor];
+    const TextureSlots ts{ od->TextureMapInfoArray, heap, resolved };
     const float* bc = od->Material.BaseColor;
-    if ((bc[0] > 0.0f || bc[1] > 0.0f || bc[2] > 0.0f || bc[3] > 0.0f) && info.Descriptor != ~0u) a *= sample_map(heap, srgbLut, info, tc).w;
+    if ((bc[0] > 0.0f || bc[1] > 0.0f || bc[2] > 0.0f || bc[3] > 0.0f) && ts.has(TEX_BaseColor)) a *= ts.sample(TEX_BaseColor, srgbLut, tc).w;
     return a >= od->Material.AlphaCutoff;
 }
 
@@ -155,33 +170,33 @@ PT_DEV bool is_opaque_visibility(const PtObjectData* od, const HeapEntry* heap, 
 }
 
 // EvaluateMaterial, ShadingHelpers.hlsli:161-235. N: shading normal (in/out), T: front tangent.
-PT_DEV PtMaterial evaluate_material(v3& N, v3 T, const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc)
+PT_DEV PtMaterial evaluate_material(v3& N, v3 T, const PtObjectData* od, const HeapEntry* heap, const float* srgbLut, const TexCoords& tc, const HeapEntry* resolved = nullptr)
 {
     PtMaterial m = od->Material;
-    const PtTextureMapInfo* ti = od->TextureMapInfoArray;
-    if ((m.BaseColor[0] > 0.0f || m.BaseColor[1] > 0.0f || m.BaseColor[2] > 0.0f || m.BaseColor[3] > 0.0f) && ti[TEX_BaseColor].Descriptor != ~0u) {
-        const f4 t = sample_map(heap, srgbLut, ti[TEX_BaseColor], tc);
+    const TextureSlots ts{ od->TextureMapInfoArray, heap, resolved };
+    if ((m.BaseColor[0] > 0.0f || m.BaseColor[1] > 0.0f || m.BaseColor[2] > 0.0f || m.BaseColor[3] > 0.0f) && ts.has(TEX_BaseColor)) {
+        const f4 t = ts.sample(TEX_BaseColor, srgbLut, tc);
         m.BaseColor[0] *= t.x; m.BaseColor[1] *= t.y; m.BaseColor[2] *= t.z; m.BaseColor[3] *= t.w;
     }
     const v3 em = V3(m.EmissiveColor) * m.EmissiveStrength;
-    if ((em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) && ti[TEX_EmissiveColor].Descriptor != ~0u) {
-        const f4 t = sample_map(heap, srgbLut, ti[TEX_EmissiveColor], tc);
+    if ((em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) && ts.has(TEX_EmissiveColor)) {
+        const f4 t = ts.sample(TEX_EmissiveColor, srgbLut, tc);
         m.EmissiveColor[0] *= t.x; m.EmissiveColor[1] *= t.y; m.EmissiveColor[2] *= t.z;
     }
-    if (ti[TEX_MetallicRoughness].Descriptor != ~0u) {
+    if (ts.has(TEX_MetallicRoughness)) {
         if (m.Metallic > 0.0f || m.Roughness > 0.0f) {
-            const f4 t = sample_map(heap, srgbLut, ti[TEX_MetallicRoughness], tc);
+            const f4 t = ts.sample(TEX_MetallicRoughness, srgbLut, tc);
             m.Metallic *= t.z; m.Roughness *= t.y;
         }
     } else {
-        if (m.Metallic > 0.0f && ti[TEX_Metallic].Descriptor != ~0u) m.Metallic *= sample_map(heap, srgbLut, ti[TEX_Metallic], tc).x;
-        if (m.Roughness > 0.0f && ti[TEX_Roughness].Descriptor != ~0u) m.Roughness *= sample_map(heap, srgbLut, ti[TEX_Roughness], tc).x;
+        if (m.Metallic > 0.0f && ts.has(TEX_Metallic)) m.Metallic *= ts.sample(TEX_Metallic, srgbLut, tc).x;
+        if (m.Roughness > 0.0f && ts.has(TEX_Roughness)) m.Roughness *= ts.sample(TEX_Roughness, srgbLut, tc).x;
     }
     if (m.Metallic < 1.0f) {
-        if (m.Transmission > 0.0f && ti[TEX_Transmission].Descriptor != ~0u) m.Transmission *= sample_map(heap, srgbLut, ti[TEX_Transmission], tc).x;
+        if (m.Transmission > 0.0f && ts.has(TEX_Transmission)) m.Transmission *= ts.sample(TEX_Transmission, srgbLut, tc).x;
     }
-    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && ti[TEX_Normal].Descriptor != ~0u) {        // PerturbNormal :89-103
-        const f4 t = sample_map(heap, srgbLut, ti[TEX_Normal], tc);
+    if ((T.x != 0.0f || T.y != 0.0f || T.z != 0.0f) && ts.has(TEX_Normal)) {        // PerturbNormal :89-103
+        const f4 t = ts.sample(TEX_Normal, srgbLut, tc);
         const float nx = t.x * 2.0f - 1.0f, ny = t.y * 2.0f - 1.0f;                                 // [MathLib] Geometry::UnpackLocalNormal
         const float nz = ml_sqrt01(1.0f - (nx * nx + ny * ny));
         const v3 Tn = normalize(T - N * dot(N, T));                                                 // Math::CalculateTBN, Math.hlsli:17-21

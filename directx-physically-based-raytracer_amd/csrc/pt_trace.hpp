@@ -266,6 +266,7 @@ struct AlphaContext {
     const HeapEntry* heap;
     const float* srgbLut;
     const struct InstanceRecord* instances;
+    const HeapEntry* shadeTex = nullptr;      // the objects' resolved texture slots (pt_texture.hpp TextureSlots), or null
 };
 
 __device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext ac, uint32_t inst, uint32_t geom, uint32_t prim, float u, float v)
@@ -273,7 +274,7 @@ __device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext
     const PtObjectData* od = &ac.objects[ac.instances[inst].instanceID + geom];
     TexCoords tc;
     get_texture_coordinates(od, ac.heap, prim, u, v, tc);
-    return is_opaque(od, ac.heap, ac.srgbLut, tc);
+    return is_opaque(od, ac.heap, ac.srgbLut, tc, ac.shadeTex ? ac.shadeTex + (size_t)(ac.instances[inst].instanceID + geom) * kTextureSlots : nullptr);
 }
 
 // commit() for a candidate of a geometry without D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE: the alpha test runs only

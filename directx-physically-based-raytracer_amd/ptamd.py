@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libptamd.so")
 _LIB = None
 
 EXPORTS = [
-    "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync", "pt_set_frames_in_flight",
+    "pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_sync", "pt_set_frames_in_flight", "pt_set_round_chains",
     "pt_heap_resize", "pt_heap_set_buffer", "pt_heap_set_texture", "pt_build_bottom_level", "pt_update_bottom_level", "pt_release_bottom_level", "pt_skin_mesh",
     "pt_build_top_level", "pt_get_accel_stats", "pt_share_scene", "pt_set_camera", "pt_set_scene_data", "pt_set_object_data", "pt_invalidate_object_data",
     "pt_set_instance_data", "pt_set_sharding", "pt_local_rows", "pt_deinterleave_bands", "pt_gbuffer_render",
@@ -101,6 +101,7 @@ def load_library():
         lib.pt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         lib.pt_sync.argtypes = [C.c_void_p]
         lib.pt_set_frames_in_flight.argtypes = [C.c_void_p, C.c_uint32]
+        lib.pt_set_round_chains.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_heap_resize.argtypes = [C.c_void_p, C.c_uint32]
         lib.pt_heap_set_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32]
         lib.pt_heap_set_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -190,6 +191,10 @@ class DeviceContext:
 
     def set_frames_in_flight(self, n):
         self.check(self.lib.pt_set_frames_in_flight(self.handle, n))
+
+    def set_round_chains(self, n):
+        """0 = the library's choice; n independent chains of launches per frame (pt_set_round_chains)."""
+        self.check(self.lib.pt_set_round_chains(self.handle, n))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -1568,11 +1568,15 @@ uint64_t or_raytrace_render(const OrScene* s, const OrCamera* cam, const OrScene
                     if (pdf == 0.0f) break;                                             /* :336 */
                     f3 f = bsdf_eval_lobe(&bs, &sv, L, V, w, lobe, gs->ExtFlags);
                     if (f.x == 0.0f && f.y == 0.0f && f.z == 0.0f) break;               /* :342 */
-                    throughput = mul3(throughput, F3(f.x / pdf, f.y / pdf, f.z / pdf)); /* :346 */
+                    { /* :346. float3 / float is ONE IEEE reciprocal and three products (arithmetic spec, DESIGN.md section 1: HLSL does not pin
+                       * `currentThroughput / PDF` to three divisions either) */
+                        const float ipdf = 1.0f / pdf;
+                        throughput = mul3(throughput, F3(f.x * ipdf, f.y * ipdf, f.z * ipdf));
+                    }
                     if (gs->IsRussianRouletteEnabled && bounce > 3) {                   /* :348-356 */
                         float p = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
                         if (or_rng_float(&rng) >= p) break;
-                        throughput = F3(throughput.x / p, throughput.y / p, throughput.z / p);
+                        { const float ip = 1.0f / p; throughput = F3(throughput.x * ip, throughput.y * ip, throughput.z * ip); }   /* :355, same rule */
                     }
                     if (ml_luminance(throughput) <= gs->ThroughputThreshold) break;     /* :361 */
                 }

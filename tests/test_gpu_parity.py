@@ -507,6 +507,68 @@ def test_streaming_and_lockstep_schedules_agree(gpu, ptamd, pkg):
             assert rays == results[0][1] and np.array_equal(img, results[0][0])
 
 
+def test_round_chains_do_not_change_the_image(gpu, ptamd, pkg):
+    """pt_set_round_chains: the rounds of a frame as 1..4 independent chains over groups of sub-queues. On the default stream the chains run
+    one after the other (no concurrency: this pins the group arithmetic -- which block serves which sub-queue, the grids of a part of the
+    queue); with a caller's stream every chain is a graph on a stream of its own (test_round_chains_on_streams). Fused form (Cornell) and
+    streaming form (a mesh beyond LDS), incl. group sizes that do not divide the 32 / 128 sub-queues."""
+    S = pkg.scenes
+    W, H = 320, 180
+    scenes = [S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True), S.sponza_scale(n_side=48, aspect=W / H)]
+    scenes[1].scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    gs = S.graphics_settings(W, H, spp=2, bounces=5, frame_index=3)
+    try:
+        for scene in scenes:
+            ref = None
+            for n in (1, 2, 3, 4):
+                gpu.set_round_chains(n)
+                out, c = gpu_render(ptamd, gpu, scene, gs, W, H)
+                assert c.StackOverflows == 0
+                if ref is None:
+                    ref = (out, c)
+                else:
+                    assert c.SecondaryRays == ref[1].SecondaryRays, n
+                    assert np.array_equal(out["RadianceF32"].view(np.uint32), ref[0]["RadianceF32"].view(np.uint32)), n
+            gpu.set_round_chains(3)                                  # a shard: fewer tiles than sub-queues in some groups
+            part, cp = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(1, 4, 16))
+            gpu.set_round_chains(1)
+            part1, cp1 = gpu_render(ptamd, gpu, scene, gs, W, H, sharding=(1, 4, 16))
+            assert cp.SecondaryRays == cp1.SecondaryRays and np.array_equal(part["Radiance"], part1["Radiance"])
+    finally:
+        gpu.set_round_chains(0)
+
+
+def test_round_chains_on_streams(ptamd, pkg):
+    """The product form of the chains: a context on a caller's stream replays every chain as a linear graph on a stream of its own, forked from and
+    joined to the caller's stream. Several frames back to back (each frame's preamble must wait for the previous frame's chains; the G-buffer
+    pass of the next frame rewrites textures the chains read) must equal the frames rendered with one chain."""
+    import torch
+    S = pkg.scenes
+    W, H = 320, 180
+    for scene in (S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True), S.sponza_scale(n_side=48, aspect=W / H)):
+        settings = [S.graphics_settings(W, H, spp=2, bounces=5, frame_index=f) for f in range(4)]
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx = ptamd.DeviceContext(0, stream=stream.cuda_stream)
+            try:
+                g = ptamd.Scene(ctx, scene)
+                r = ptamd.Renderer(ctx, g, W, H, with_f32=True)
+                frames = {}
+                for n in (1, 3, 2, 4):
+                    ctx.set_round_chains(n)
+                    outs = []
+                    for gs in settings:                               # enqueued without waiting in between
+                        r.render(gs)
+                        outs.append(r.textures["RadianceF32"].clone())    # stream-ordered behind the frame
+                    ctx.sync()
+                    frames[n] = [o.cpu().numpy() for o in outs]
+                for n in (3, 2, 4):
+                    for f in range(len(settings)):
+                        assert np.array_equal(frames[n][f].view(np.uint32), frames[1][f].view(np.uint32)), (scene.name, n, f)
+            finally:
+                ctx.close()
+
+
 def test_deterministic_and_sharding_invariant(gpu, ptamd, pkg):
     """Run twice: bit-identical. Render as rank r of 3 and of 8: the assembled frame equals the unsharded one
     (RNG seeds and camera rays use global pixel coordinates)."""
