@@ -763,9 +763,10 @@ static uint32_t round_records_in_lds(const Context& c, const SceneView& sv) { re
 // chains > 1 (launch_raytrace): every chain is a linear hipGraph of its own, replayed on a stream of its own behind an event recorded after the
 // preamble, and the context's stream waits for all of them -- the tail of one chain's launch (a few long walks, a few blocks) overlaps the other
 // chains' launches. That is what several frames in flight do BETWEEN frames, done inside ONE frame: what a renderer that presents one frame at a
-// time needs (the reference: Source/App.cpp:167). (Parallel branches inside one captured graph -- fork / join events during capture -- were the
-// first form: on ROCm 7.2 their kernels ran without waiting for the fork point and faulted; plain streams and events are what frames in flight
-// have always used here.)
+// time needs (the reference: Source/App.cpp:167). The gain is small, and the reason is instructive: the chains are statistically identical, so
+// their launches start and drain together -- every chain still pays (rounds x the longest walk of a round), which is the critical path of a
+// frame; frames in flight hide it because their phases differ. Plain streams and events, as frames in flight use them (parallel branches inside
+// ONE captured graph were measured too: the same times on C2).
 #ifndef PT_AB_CHAINS
 #define PT_AB_CHAINS 3
 #endif
@@ -784,7 +785,15 @@ static uint32_t frame_chains(const Context& c, bool ownStreams)
 {
     // on streams of their own: the library's choice unless the caller made one; direct launches (per-launch events, the default stream): only
     // what the caller asked for, one chain after the other on the context's stream
-    const uint32_t want = c.chains ? c.chains : (ownStreams ? (uint32_t)PT_AB_CHAINS : 1u);
+    // The library's choice, from the A/B runs in profiles/r04_ab/frame_chains.jsonl: three chains for the streaming form when the frame has the GPU
+    // to itself (C3 +2 %, C5 +7.5 %, c3t +2 % per frame), one otherwise -- the fused round kernel gains nothing (C2 -1 %), and with other frames
+    // in flight the extra streams only crowd the three hardware queues the runtime exposes (C3 -40 %; four chains: -35 % even alone).
+#ifdef PT_AB_CHAINS_FORCE
+    const uint32_t choice = PT_AB_CHAINS_FORCE;                   // A/B builds: this many chains whatever the form
+#else
+    const uint32_t choice = (frame_form(c).streaming && c.framesInFlight <= 1) ? (uint32_t)PT_AB_CHAINS : 1u;
+#endif
+    const uint32_t want = c.chains ? c.chains : (ownStreams ? choice : 1u);
     return std::max(1u, std::min({ want, Context::kMaxChains, 1u << c.sqShift }));
 }
 

@@ -195,6 +195,9 @@ PT_DEV void reconstruct_hit(const SceneView& sv, const HitGeometry& hg, uint32_t
     // GetTextureCoordinates (ShadingHelpers.hlsli:32-51, called at RaytracingHelpers.hlsli:124-130) from the resolved geometry and the
     // triangle's indices at hand: the same three vertices, fetched in the dependency level of the tangents instead of behind
     // object record -> two heap entries -> three index loads
+#ifdef PT_AB_OLD_TEXTURE_PATH
+    get_texture_coordinates(&sv.objects[h.ObjectIndex], sv.heap, prim, bu, bv, h.TextureCoordinates); return;      // A/B builds: the path of rounds 1-3
+#endif
     #pragma unroll
     for (int i = 0; i < 2; i++) {
         h.TextureCoordinates.uv[i][0] = h.TextureCoordinates.uv[i][1] = 0.0f;
@@ -223,7 +226,11 @@ PT_DEV PtMaterial surface_material(const SceneView& sv, SurfaceHit& h, ObjectTab
         return m;
     }
     return evaluate_material(h.ShadingNormal, h.IsFrontFace ? h.Tangent : -h.Tangent, &sv.objects[h.ObjectIndex], sv.heap, sv.srgbLut,
+#ifdef PT_AB_OLD_TEXTURE_PATH
+                             h.TextureCoordinates, nullptr);
+#else
                              h.TextureCoordinates, sv.shadeTex ? sv.shadeTex + (size_t)h.ObjectIndex * kTextureSlots : nullptr);   // ShadingHelpers.hlsli:161-235
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ uint32_t lds[32];                                  // two sets of reservation words, taken in turn: a fast wave may enter the next tile's reservation while a slow one still reads this tile's
     uint32_t emits = 0;
     const PtCamera& cam = fc->cam; const PtSceneData& sd = fc->sd; const PtGraphicsSettings& gs = fc->gs;
-    const uint32_t nsq = 1u << sqShift, sq = blockIdx.x & (nsq - 1u), bq = blockIdx.x >> sqShift, nbq = gridDim.x >> sqShift;
+    const uint32_t nsq = 1u << sqShift, bq = blockIdx.x / sqCount, sq = sqBase + (blockIdx.x - bq * sqCount), nbq = gridDim.x / sqCount;   // this launch serves sub-queues [sqBase, sqBase + sqCount): one chain of the frame
     const uint32_t nT = countIn[sq], nF = countIn[nsq + sq];
     const uint32_t seg = sq * segCap;
 

@@ -274,7 +274,11 @@ __device__ __attribute__((noinline)) bool candidate_is_opaque(const AlphaContext
     const PtObjectData* od = &ac.objects[ac.instances[inst].instanceID + geom];
     TexCoords tc;
     get_texture_coordinates(od, ac.heap, prim, u, v, tc);
+#ifdef PT_AB_OLD_TEXTURE_PATH
+    return is_opaque(od, ac.heap, ac.srgbLut, tc);
+#else
     return is_opaque(od, ac.heap, ac.srgbLut, tc, ac.shadeTex ? ac.shadeTex + (size_t)(ac.instances[inst].instanceID + geom) * kTextureSlots : nullptr);
+#endif
 }
 
 // commit() for a candidate of a geometry without D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE: the alpha test runs only

@@ -175,8 +175,9 @@ int  pt_set_frames_in_flight(PtContext* ctx, uint32_t frames);
 /* Chains of a frame. Paths never leave their sub-queue of the path queue, so after the first bounce the rounds of a group of sub-queues depend
  * on nothing outside the group: the library runs `chains` such groups as independent chains of launches, each on a stream of its own (forked
  * from and joined to the context's stream, invisible to the caller), so that ONE frame's launches overlap the way frames in flight do -- for a
- * host that presents one frame at a time (the reference: Source/App.cpp:167). 0 = the library's choice (3 on a caller-provided stream; 1 on the
- * default stream and while kernel timing is enabled, where the chains run one after the other). The image does not depend on it. */
+ * host that presents one frame at a time (the reference: Source/App.cpp:167). 0 = the library's choice: 3 for a scene beyond LDS rendered on a
+ * caller-provided stream with pt_set_frames_in_flight(1), else 1 (measured: profiles/r04_ab/frame_chains.jsonl). On the default stream and while
+ * kernel timing is enabled the chains run one after the other. The image does not depend on it. */
 int  pt_set_round_chains(PtContext* ctx, uint32_t chains);            /* 0..4 */
 
 /* ------------------------------------------------------------------------------------------
