@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: independent contexts on separate HIP streams, so the launch-bound tail "
                          "rounds of one frame overlap the wide rounds of the next")
+    ap.add_argument("--chains", type=int, default=0,
+                    help="pt_set_round_chains: independent chains of launches per frame (0 = the library's choice: 3 for a scene beyond LDS when a frame has the GPU "
+                         "to itself, else 1). --chains 1 for a kernel trace in which every launch ran alone")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer aid: skip the per-launch HIP events (and with them the roofline object), so the timed region replays hipGraphs")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -249,6 +252,7 @@ def main():
                 self.ctx = P.DeviceContext(local_rank, stream=self.stream.cuda_stream)
                 self.ctx.set_sharding(rank, args.emulate_world if args.emulate_world else world, BAND)
                 self.ctx.set_frames_in_flight(max(1, args.inflight))
+                self.ctx.set_round_chains(args.chains)
                 self.scene = P.Scene(self.ctx, scene, device) if owner is None else P.SharedScene(self.ctx, owner.scene)
                 self.renderer = P.Renderer(self.ctx, self.scene, W, H)
                 self.full = torch.zeros((H, W, 4), dtype=torch.int16, device=device) if (rank == 0 and collective) else None
@@ -336,7 +340,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frames_per_s": args.steps / elapsed, "mrays_per_s_per_gpu": rays_total / elapsed / 1e6 / world,
             "rays_per_frame": rays_total / args.steps, "host_enqueue_ms_per_step": enqueue_s / args.steps * 1e3,
-            "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes),
+            "config": {"workload": desc, "width": W, "height": H, "spp": spp, "bounces": bounces, "frames_in_flight": len(lanes), "round_chains": args.chains or "library's choice",
                        "scene_copies_per_gpu": 1, "russian_roulette": True, "triangles": scene.triangle_count, "instances": len(scene.objects),
                        "bvh": {"node_bytes": acc.NodeSizeBytes, "nodes_total_bytes": acc.NodeBytes, "triangles_total_bytes": acc.TriangleBytes,
                                "bottom_level_depth": acc.MaxBottomLevelDepth, "top_level_depth": acc.TopLevelDepth, "traversal_copy_bytes": acc.BlobBytes},

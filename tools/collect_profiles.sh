@@ -12,9 +12,9 @@ for w in $WL; do
   timeout -k 10 400 python3 bench.py --workload $w $extra > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err || echo "bench $w failed"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${w}_stats -o p --output-format csv -- python3 bench.py --workload $w --no-cpu-baseline > $OUT/${w}_bench_under_rocprof.json 2> $OUT/${w}_rocprof.err || echo "rocprof $w failed"
   cp $OUT/${w}_stats/p_kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
-  # one frame at a time (--inflight 1): every launch of the trace ran alone on the GPU, so the CSV's average duration of the dominant kernel is
+  # one frame at a time, one chain (--inflight 1 --chains 1): every launch of the trace ran alone on the GPU, so the CSV's average duration of the dominant kernel is
   # the figure bench.py's roofline object quotes from its own HIP events (the pipelined trace above mixes overlapped and solo launches)
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${w}_stats1 -o p --output-format csv -- python3 bench.py --workload $w --inflight 1 --no-cpu-baseline > $OUT/${w}_inflight1_bench_under_rocprof.json 2> $OUT/${w}_rocprof1.err || echo "rocprof inflight1 $w failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${w}_stats1 -o p --output-format csv -- python3 bench.py --workload $w --inflight 1 --chains 1 --no-cpu-baseline > $OUT/${w}_inflight1_bench_under_rocprof.json 2> $OUT/${w}_rocprof1.err || echo "rocprof inflight1 $w failed"
   cp $OUT/${w}_stats1/p_kernel_stats.csv $OUT/${w}_inflight1_kernel_stats.csv 2>/dev/null
   bash tools/pmc.sh final_$w $w > /dev/null 2>&1
   cp gpurun_out/pmc_final_$w/summary.txt $OUT/${w}_pmc_summary.txt

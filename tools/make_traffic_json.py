@@ -24,9 +24,9 @@ traffic = {"_doc": "HBM bytes per launch from rocprofv3 PMC passes: FETCH_SIZE x
                    "divided by the dispatch count, for the variant of each kernel the workload runs; valu: SQ_INSTS_VALU of all kernels of one frame. "
                    "lanes_per_instruction: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), each divided by its number of passes, per kernel. Sources: profiles/r04_<workload>_pmc_summary.txt. source_hash = bench.source_hash() of the kernel sources measured."}
 for f in os.listdir(SRC):                    # everything that is not a per-workload file (extras of tools/collect_profiles.sh)
-    if os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err") and not f.startswith(("c2_b", "c2_k", "c2_p", "c3_", "c5_")):
+    if os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err") and not f.startswith(("c2_b", "c2_k", "c2_p", "c2_i", "c3_", "c3t_", "c5_")):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, ROUND + f))
-for w in ("c2", "c3", "c5"):
+for w in [w for w in ("c2", "c3", "c3t", "c5") if os.path.exists(os.path.join(SRC, w + "_pmc_summary.txt"))]:
     for f in os.listdir(SRC):
         if f.startswith(w + "_") and os.path.isfile(os.path.join(SRC, f)) and not f.endswith(".err"):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, ROUND + f))
@@ -34,7 +34,7 @@ for w in ("c2", "c3", "c5"):
     ent = {"source_hash": bench.source_hash()}
     # the kernels of the product path of this workload (the statistics frame of bench.py runs other variants: not counted)
     product = ("k_round<false", "k_gbuffer<false", "k_pt_init", "k_pt_first", "k_set_constants", "k_capture_normals") if w == "c2" else \
-              ("k_shade<false", "k_extend_stream<false", "k_gbuffer<false", "k_pt_init", "k_pt_first", "k_set_constants", "k_capture_normals")
+              (("k_shade<true" if w == "c3t" else "k_shade<false"), "k_extend_stream<false", "k_gbuffer<false", "k_pt_init", "k_pt_first", "k_set_constants", "k_capture_normals")
     frames = max(c["SQ_INSTS_VALU"][1] for k, c in pm.items() if "k_gbuffer<false" in k and "SQ_INSTS_VALU" in c)   # one G-buffer launch per frame
     valu_total = 0.0
     lanes = {}
