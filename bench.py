@@ -393,7 +393,6 @@ def main():
         QUEUE, GEOM, CONTRACT = 160.0, 108.0, 300.0              # CONTRACT: SURVEY 8(d)'s B_state per ray (adds the 32 B hit record round trip), reported apart
         geom = 0.0 if geometry_in_lds else GEOM
         STATE = {"k_round": QUEUE + geom, "k_extend": 48.0, "k_shade": QUEUE + GEOM}
-        hbm_bvh = 0.0 if blob_in_lds else bvh_bytes_per_ray
 
         def gbps(nbytes, ms):
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -404,19 +403,29 @@ def main():
         # entry per primary-hit pixel and sample after the first over a frame -- primary-surface record 48 r, state 48 r + 48 w, first ray 32 w
         FRESH = 48.0 + 48.0 + 48.0 + 32.0
         fresh_entries = hit_pixels * (spp - 1) * args.steps     # over the timed single-stream pass
+        # BVH bytes of a traversal launch that HBM has to deliver: what the rays touch, but never more than the traversal copy itself -- a byte of it
+        # that L2 / Infinity Cache hold is fetched from HBM at most once per launch, however many rays read it (C3: 690 k rays x 1.42 KB touch
+        # 980 MB of a 30 MB copy). SURVEY 8(d)'s B_bvh, every touched byte, is what contract_frac prices.
+        def bvh_hbm_bytes(launches):
+            if blob_in_lds or not launches:
+                return 0.0
+            return launches * min(solo_secondary / launches * bvh_bytes_per_ray, float(acc.BlobBytes))
+
         kernels = {}
         for name, key in (("k_round", "round"), ("k_extend", "extend"), ("k_shade", "shade")):
-            if ks.get(key + "_launches", 0):
-                per_ray = STATE[name] + (hbm_bvh if name in ("k_round", "k_extend") else 0.0)
+            n = ks.get(key + "_launches", 0)
+            if n:
+                traversal = name in ("k_round", "k_extend")
                 fresh = fresh_entries * FRESH if name in ("k_round", "k_shade") else 0.0
-                kernels[name] = {"ms": ks[key + "_ms"], "launches": ks[key + "_launches"], "bytes": solo_secondary * per_ray + fresh,
-                                 "contract_bytes": solo_secondary * (CONTRACT + (bvh_bytes_per_ray if name != "k_shade" else 0.0)) + fresh if name != "k_extend" else None}
+                kernels[name] = {"ms": ks[key + "_ms"], "launches": n, "bytes": solo_secondary * STATE[name] + (bvh_hbm_bytes(n) if traversal else 0.0) + fresh,
+                                 "contract_bytes": solo_secondary * ((CONTRACT if name != "k_extend" else STATE[name]) + (bvh_bytes_per_ray if traversal else 0.0)) + fresh}
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         kd = kernels[dom]
         # step level: every byte a frame has to move through HBM by construction of the data layout
         shade_per_ray = (QUEUE + geom) if "k_round" in kernels else (QUEUE + 32.0 + GEOM)     # two-kernel form: + hit record w + r
         frame_bytes = (W * H * 63.0 + hit_pixels * (47.0 + 48.0 + 48.0 + 32.0)          # G-buffer stores; k_pt_first: G-buffer read, primary-surface record written, the first sample's first bounce shaded in place: state + ray written
-                       + solo_secondary / args.steps * (shade_per_ray + hbm_bvh)         # traced entries
+                       + solo_secondary / args.steps * shade_per_ray                     # traced entries
+                       + bvh_hbm_bytes(ks.get("extend_launches", 0) or ks.get("round_launches", 0)) / args.steps   # BVH bytes HBM must deliver (0: LDS-resident)
                        + hit_pixels * (spp - 1) * FRESH                                  # fresh entries of the later samples
                        + W * H * 8.0)                                                    # radiance out
         contract_bytes = solo_secondary / args.steps * (CONTRACT + bvh_bytes_per_ray) + W * H * (63.0 + 8.0 + 32.0)
@@ -446,7 +455,8 @@ def main():
             "definition": "achieved = algorithmic HBM bytes per launch of the dominant kernel / its average launch duration (per-launch HIP events on the "
                           "kernel's stream, single stream, after the timed region); bytes served from LDS are not counted (geometry_served_from); "
                           "traffic = PMC (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/traffic.json, traffic_frac = that / the same duration; "
-                          "contract_frac = SURVEY 8(d)'s 300 B per ray + BVH bytes wherever they are served from; frame.* = the same for a whole frame",
+                          "contract_frac = SURVEY 8(d)'s B_state (300 B per ray) + B_bvh (every BVH byte the rays touch, wherever it is served from: LDS on small scenes, "
+                          "mostly L2 on large ones -- it can exceed 1); frame.* = the same for a whole frame",
             "geometry_served_from": "LDS (object table + normal records staged per launch): not counted" if geometry_in_lds else "memory: 108 B per ray counted",
             "dominant_kernel": {"name": dom, "avg_launch_ms": dom_ms, "launches_timed": kd["launches"],
                                 "algorithmic_bytes_per_launch": kd["bytes"] / max(1, kd["launches"]),
@@ -464,7 +474,9 @@ def main():
                           "frac": gbps(frame_bytes, ms_per_step) / HBM_PEAK_GBS},
             "bvh": {"bytes_per_ray": bvh_bytes_per_ray, "nodes_per_ray": cs.NodesVisited / all_rays, "tris_per_ray": cs.TrianglesTested / all_rays,
                     "longest_walk_nodes": cs.MaxNodesPerRay or None,
-                    "served_from": "LDS (the traversal copy is staged by every block): not HBM traffic" if blob_in_lds else "L2 / Infinity Cache / HBM: counted in the HBM bytes above"},
+                    "traversal_copy_bytes": acc.BlobBytes,
+                    "served_from": "LDS (the traversal copy is staged by every block): not HBM traffic" if blob_in_lds
+                                   else "L2 / Infinity Cache / HBM: per launch, min(bytes touched, traversal_copy_bytes) counted as HBM bytes; every touched byte in contract_frac"},
         }
         if traffic_note:
             result["roofline"]["traffic_note"] = traffic_note
@@ -475,7 +487,7 @@ def main():
         if valu:
             nominal = props.multi_processor_count * 4 * clock_hz / 2.0
             peak_issue, peak_occ, peak_src = nominal, None, "nominal: CUs x 4 SIMD-32 x clock / 2 cycles per wave64 instruction"
-            vp = os.path.join(ROOT, "profiles", "r03_valu_peak.json")
+            vp = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_valu_peak.json", "r03_valu_peak.json")) if os.path.exists(p)), "")
             if os.path.exists(vp):
                 try:
                     vj = json.load(open(vp))
