@@ -71,6 +71,7 @@ void pt_destroy(PtContext* ctx)
     Context& c = ctx->c;
     hipSetDevice(c.device);
     hipStreamSynchronize(c.stream);
+    for (hipStream_t st : c.chainStream) if (st) hipStreamSynchronize(st);       // (the context's stream has waited for them already: every frame joins its chains)
     pt_comm_destroy(ctx);
     // an owner that is still viewed (pt_share_scene): its viewers lose the scene -- their next render answers PT_ERROR_NOT_READY -- after
     // their streams have drained, and never touch this context again

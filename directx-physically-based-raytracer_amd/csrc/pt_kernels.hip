@@ -976,7 +976,7 @@ hipError_t launch_raytrace(Context& c, const SceneView& sv, const FrameView& fv,
     const bool graphable = c.stream != nullptr && !c.timing && !c.disableGraphs &&
                            (c.debugFlags & ~(PT_DEBUG_UNFUSED_ROUNDS | PT_DEBUG_TRAVERSAL_PHASED | PT_DEBUG_LOCKSTEP | PT_DEBUG_GATHER_LOCAL_ONLY | PT_DEBUG_GATHER_SELF_EXCHANGE)) == 0;   // counters / validation variants launch directly
     auto capture = [&](hipStream_t s, hipGraphExec_t& exec, auto&& body) -> hipError_t {          // one linear graph from what `body` enqueues on s
-        if (exec) { hipGraphExecDestroy(exec); exec = nullptr; }
+        if (exec) { hipStreamSynchronize(c.stream); hipGraphExecDestroy(exec); exec = nullptr; }   // its last replay may still be running (once per change of scene / frame geometry)
         hipGraph_t graph = nullptr;
         hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
         if (ce == hipSuccess) {
