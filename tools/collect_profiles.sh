@@ -24,7 +24,7 @@ if [[ " $WL " == *" extras "* ]]; then
   timeout -k 10 200 python3 bench.py --workload dynamic --no-cpu-baseline > $OUT/dynamic_bench.json 2> $OUT/dynamic_bench.err || echo "dynamic failed"
   timeout -k 10 200 python3 bench.py --rehearse-collective --no-cpu-baseline > $OUT/c2_rehearse_collective.json 2> $OUT/c2_rehearse_collective.err || echo "rehearse failed"
   timeout -k 10 200 python3 bench.py --workload c4 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/c4_bench.json 2> $OUT/c4_bench.err || echo "c4 failed"
-  for n in 2 4 8; do timeout -k 10 200 python3 bench.py --emulate-world $n --no-cpu-baseline > $OUT/c2_emulate_world_$n.json 2> /dev/null || echo "emulate $n failed"; done
+  for n in 2 4 8; do timeout -k 10 200 python3 bench.py --emulate-world $n --steps 120 --warmup 6 --no-cpu-baseline > $OUT/c2_emulate_world_$n.json 2> /dev/null || echo "emulate $n failed"; done     # 120 steps: a shard's frame is 0.4 ms, fill and drain of three lanes are a tenth of 20 of them
   timeout -k 10 200 python3 tools/build_prof.py c3 c5 > $OUT/build_times.txt 2>&1 || echo "build_prof failed"
   ( cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/build_stats -o b -- python3 $GRAFT_REPO_ROOT/tools/build_prof.py c3 > /dev/null 2>&1 )
   cp $OUT/build_stats/b_kernel_stats.csv $OUT/build_c3_kernel_stats.csv 2>/dev/null
