@@ -136,3 +136,30 @@ def test_gather_plans_pair_up_and_tile_the_frame(ptamd):
                     assert np.all(covered == 1)
     with pytest.raises(ptamd.PtInvalidArgument):
         ptamd.gather_plan(16, 64, 0, 2, 16, root=2)
+
+
+def test_textured_sponza_scale_scene(pkg, oracle):
+    """scenes.sponza_scale(textured=True), the workload of `bench.py --workload c3t` (BASELINE configs[2] says "Sponza-scale glTF"): the geometry of
+    the untextured scene, plus UVs, tangents, three textures per material and three alpha-masked strips -- checked here at a small size on
+    the CPU (the full size runs under -m gpu): layout of the heap and the object data, and that the oracle sees through the lattice."""
+    S, L = pkg.scenes, pkg.layouts
+    plain = S.sponza_scale(n_side=48, aspect=2.0)
+    tex = S.sponza_scale(n_side=48, aspect=2.0, textured=True, texture_size=32)
+    assert tex.triangle_count == plain.triangle_count
+    assert np.array_equal(tex.nodes[0].meshes[7].vertices["Position"], plain.nodes[0].meshes[7].vertices["Position"])
+    kinds = [h.kind for h in tex.heap]
+    assert kinds.count(S.KIND_TEXTURE2D) == 3 * 24 and kinds.count(S.KIND_BUFFER) == 2 * 25
+    od = tex.object_data
+    assert int((od["Material"]["AlphaMode"] == 1).sum()) == 3
+    used = od["TextureMapInfoArray"]["Descriptor"][:24] != L.NONE
+    assert used[:, [0, 4, 6]].all() and not used[:, [1, 2, 3, 5]].any()             # BaseColor, MetallicRoughness, Normal
+    assert np.all(od["VertexDesc"]["Tangent"][:24] == 18) and np.all(od["VertexDesc"]["TexCoord"][:24, 0] == 24)
+    W, H = 96, 48
+    gs = S.graphics_settings(W, H, spp=1, bounces=2)
+    tex.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+    a, rays_a, _ = oracle.render(tex, gs, accel_mode=1, layouts=L)
+    for m in tex.nodes[0].meshes:
+        m.material["AlphaMode"] = 0
+    tex.finalize()
+    b, rays_b, _ = oracle.render(tex, gs, accel_mode=1, layouts=L)
+    assert rays_a > 0 and not np.array_equal(a["Position"], b["Position"])          # some primary rays pass through the masked strips' cut-outs

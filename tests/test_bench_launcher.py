@@ -34,3 +34,27 @@ def test_gpus_must_match_world_size_under_torchrun():
 def test_no_exec_family_call_in_bench():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os.exec" not in src and "execv" not in src
+
+
+def test_cpu_baseline_states_the_cores_it_really_uses():
+    """`cores` used to be os.cpu_count() (256 on the GPU box, whose cgroup grants the job 16). The baseline now reports the
+    affinity mask, the cgroup quota and OpenMP's default next to the thread count it uses, and a one-thread figure beside the all-thread one."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import bench
+    import __graft_entry__ as ge
+    share = bench.host_cpu_share()
+    assert share["os_cpu_count"] >= share["sched_affinity"] >= 1
+    assert share["cgroup_cpus"] is None or share["cgroup_cpus"] > 0
+    ge.load_package()
+    import dxpbrt_amd.layouts as L
+    import dxpbrt_amd.scenes as S
+    W, H = 96, 54
+    scene = S.cornell_box(aspect=W / H, variant="ggx")
+    gs = S.graphics_settings(W, H, spp=1, bounces=3)
+    out = bench.cpu_baseline(scene, gs, W, H, L, budget_s=0.5)
+    usable = share["sched_affinity"] if not share["cgroup_cpus"] else max(1, min(share["sched_affinity"], int(share["cgroup_cpus"] + 0.5)))
+    assert out["cores"] == out["threads"] == usable and out["kind"] == "port" and out["value"] > 0
+    assert out["one_thread"]["cores"] == 1 and out["one_thread"]["value"] > 0
+    assert 0 < out["parallel_efficiency"] <= 1.5 and out["host"]["sched_affinity"] == share["sched_affinity"]
+    assert np.isfinite(out["value"])
