@@ -404,8 +404,8 @@ def main():
         FRESH = 48.0 + 48.0 + 48.0 + 32.0
         fresh_entries = hit_pixels * (spp - 1) * args.steps     # over the timed single-stream pass
         # BVH bytes of a traversal launch that HBM has to deliver: what the rays touch, but never more than the traversal copy itself -- a byte of it
-        # that L2 / Infinity Cache hold is fetched from HBM at most once per launch, however many rays read it (C3: 690 k rays x 1.42 KB touch
-        # 980 MB of a 30 MB copy). SURVEY 8(d)'s B_bvh, every touched byte, is what contract_frac prices.
+        # that L2 / Infinity Cache hold is fetched from HBM at most once per launch, however many rays read it (C3: 438 k rays x 1.42 KB touch
+        # 620 MB of an 18.6 MB copy). SURVEY 8(d)'s B_bvh, every touched byte, is what contract_frac prices.
         def bvh_hbm_bytes(launches):
             if blob_in_lds or not launches:
                 return 0.0
