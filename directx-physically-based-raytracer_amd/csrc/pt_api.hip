@@ -57,6 +57,28 @@ static void detach_from_owner(Context& c)
 }
 
 static void free_blas(Blas& b) { if (b.nodes) hipFree(b.nodes); if (b.tris) hipFree(b.tris); if (b.idx) hipFree(b.idx); if (b.rootBounds) hipFree(b.rootBounds); b.tree.release(); b = Blas(); }
+// The context is about to give up its traversal copy while it keeps its bottom levels (it becomes a view of another context's scene): the
+// adopted ones get arrays of their own again. Synchronous; a rare path.
+static hipError_t materialise_adopted(Context& c)
+{
+    if (!c.blobDev) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(c.stream);
+    for (auto& kv : c.blas) {
+        Blas& b = kv.second;
+        if (!b.inBlob || e != hipSuccess) continue;
+        const uint8_t* blob = (const uint8_t*)c.blobDev;
+        const size_t nb = sizeof(WideNode) * (size_t)(b.nodeCount ? b.nodeCount : 1), tb = sizeof(TriPacket) * (size_t)(b.triCount ? b.triCount : 1), ib = 16 * (size_t)(b.triCount ? b.triCount : 1);
+        if ((e = hipMalloc((void**)&b.nodes, nb)) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&b.tris, tb)) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&b.idx, ib)) != hipSuccess) break;
+        if ((e = hipMemcpy(b.nodes, blob + b.blobNodeAt, sizeof(WideNode) * (size_t)b.nodeCount, hipMemcpyDeviceToDevice)) != hipSuccess) break;
+        if (b.triCount && (e = hipMemcpy(b.tris, blob + b.blobTriAt, sizeof(TriPacket) * (size_t)b.triCount, hipMemcpyDeviceToDevice)) != hipSuccess) break;
+        if (b.triCount && (e = hipMemcpy(b.idx, blob + b.blobIdxAt, 16 * (size_t)b.triCount, hipMemcpyDeviceToDevice)) != hipSuccess) break;
+        b.inBlob = false;
+    }
+    return e;
+}
+
 static void free_tlas(Tlas& t)
 {
     void* ptrs[] = { t.nodes, t.rootBounds, t.instances, (void*)t.blasBounds };
@@ -357,9 +379,22 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     int st = poll_tlas_header(c, false);
     if (st != PT_OK) return st;
 
-    // ---- host side: resolve ids, lay the blob out: [InstanceT x count | nodes: TLAS (reserved), then one piece per referenced
-    // bottom level | triangle packets per piece | InstanceT x count once more, in TLAS leaf order]
-    const uint32_t tlasNodeCap = wide_node_capacity(count);
+    // ---- host side: resolve ids and lay the traversal copy out:
+    //   [ nodes: top level (reserved) | one piece per bottom level ] [ triangle packets per piece ] [ vertex indices per packet ]
+    //   [ InstanceT x count (API order) ] [ InstanceT x count (top-level leaf order) ] [ entry record x count ]
+    // Everything that depends on the number of instances sits BEHIND the bottom-level data, and the top level's node reservation only moves
+    // in steps, so that the pieces keep their places from build to build: a STATIC bottom level lives in the copy only (round 4, VERDICT r3
+    // item 8). Its first top-level build copies its nodes, packets and indices in and frees the arrays the build left ("adoption"); later
+    // builds find it in place and copy nothing; when the layout does change (another set of meshes, a top level beyond its reservation) a new
+    // copy is allocated and the pieces move over from the old one. A bottom level built with ALLOW_UPDATE keeps its own arrays -- the refit
+    // writes them -- and is copied in every build, as before. Bottom levels that were adopted but are not referenced by this top level ride
+    // along, so that a later top level can still name them.
+    const uint32_t tlasNodeExact = wide_node_capacity(count);
+    uint32_t tlasNodeCap = tlasNodeExact;
+    if (count >= 64u) { tlasNodeCap = 128u; while (tlasNodeCap < tlasNodeExact) tlasNodeCap <<= 1; }   // (small scenes stay exact: their copy is staged into LDS whole)
+    if (c.blob.base && c.tlasNodeReserve >= tlasNodeExact && c.tlasNodeReserve <= 2u * tlasNodeCap) tlasNodeCap = c.tlasNodeReserve;   // keep the reservation of the last build while it fits
+    struct Piece { uint64_t id; Blas* b; uint32_t nodeBase, triBase; bool referenced; };
+    std::vector<Piece> pieces;
     std::vector<uint64_t> pieceIds;
     std::map<uint64_t, uint32_t> pieceOf;
     std::vector<BlasEntry> table;
@@ -373,10 +408,12 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     for (uint32_t i = 0; i < count; i++) {
         auto it = c.blas.find(descs[i].AccelerationStructure);
         API_ARG(&c, it != c.blas.end(), "instance refers to an unknown bottom-level id");
-        const Blas& b = it->second;
+        Blas& b = it->second;
         auto pb = pieceOf.find(descs[i].AccelerationStructure);
         if (pb == pieceOf.end()) {
-            table.push_back(BlasEntry{ b.nodes, b.tris, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris, b.idx, descs[i].InstanceID & 0xFFFFFFu, b.geometryCount });
+            pieces.push_back(Piece{ descs[i].AccelerationStructure, &b, blobNodes, blobTris, true });
+            // (pointers of the row are filled in below, once the places are known)
+            table.push_back(BlasEntry{ nullptr, nullptr, b.rootBounds, b.triCount, b.nodeCount, blobNodes, blobTris, nullptr, descs[i].InstanceID & 0xFFFFFFu, b.geometryCount });
             blobNodes += b.nodeCount; blobTris += b.triCount;
             pieceIds.push_back(descs[i].AccelerationStructure);
             pb = pieceOf.emplace(descs[i].AccelerationStructure, (uint32_t)table.size() - 1).first;
@@ -389,14 +426,26 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         objectEnd = std::max<uint64_t>(objectEnd, (uint64_t)src.instanceID + b.geometryCount);
         bindingHash = (bindingHash ^ src.instanceID) * 1099511628211ull; bindingHash = (bindingHash ^ descs[i].AccelerationStructure) * 1099511628211ull;
     }
+    for (auto& kv : c.blas)                                        // adopted, not referenced: carried along
+        if (kv.second.inBlob && !pieceOf.count(kv.first)) {
+            pieces.push_back(Piece{ kv.first, &kv.second, blobNodes, blobTris, false });
+            blobNodes += kv.second.nodeCount; blobTris += kv.second.triCount;
+        }
     const size_t instBytes = (size_t)count * sizeof(InstanceT), nodeBytes = (size_t)blobNodes * sizeof(WideNode), triBytes = (size_t)blobTris * sizeof(TriPacket);
     const size_t idxBytes = (size_t)blobTris * 16;
-    const size_t total = instBytes + nodeBytes + triBytes + instBytes + instBytes + idxBytes;   // ... | leaf-order records | entry records (same size) | vertex indices
+    const size_t nodeAt = 0, triAt = nodeBytes, idxAt = nodeBytes + triBytes, instAt = idxAt + idxBytes, leafAt = instAt + instBytes, enterAt = leafAt + instBytes;
+    const size_t total = enterAt + instBytes;
     API_ARG(&c, total / 16 < 0xFFFFFFFFull, "scene too large for 32-bit blob addressing");
+    auto node_at = [&](const Piece& p) { return nodeAt + sizeof(WideNode) * (size_t)p.nodeBase; };
+    auto tri_at = [&](const Piece& p) { return triAt + sizeof(TriPacket) * (size_t)p.triBase; };
+    auto idx_at = [&](const Piece& p) { return idxAt + 16 * (size_t)p.triBase; };
 
     // ---- capacities: everything is grow-only, so the rebuild of an unchanged scene layout (a dynamic frame) allocates nothing and
     // waits for nothing; growth waits for the stream first (kernels in flight may still read the old buffers)
-    const bool growth = count > c.tlas.capacity || !c.tlas.nodes || count > c.tlasInstanceCap || !c.tlas.instances || total > c.blobCapacity || !c.blobDev;
+    bool moved = false;                                            // an adopted piece is not where the new layout wants it
+    for (const Piece& p : pieces) if (p.b->inBlob && (p.b->blobNodeAt != node_at(p) || p.b->blobTriAt != tri_at(p) || p.b->blobIdxAt != idx_at(p))) moved = true;
+    const bool newBlob = total > c.blobCapacity || !c.blobDev || moved;
+    const bool growth = count > c.tlas.capacity || !c.tlas.nodes || count > c.tlasInstanceCap || !c.tlas.instances || newBlob;
     if (growth) API_HIP(&c, hipStreamSynchronize(c.stream));
     drop_tlas(c);
     if (count > c.tlasInstanceCap || !c.tlas.instances) {
@@ -407,11 +456,14 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
         API_HIP(&c, hipMalloc((void**)&c.tlas.blasBounds, sizeof(float*) * (count ? count : 1)));
         c.tlasInstanceCap = count ? count : 1;
     }
-    if (total > c.blobCapacity || !c.blobDev) {
-        if (c.blobDev) hipFree(c.blobDev);
+    void* oldBlob = nullptr;                                       // pieces move over from it; freed once the moves have run
+    if (newBlob) {
+        oldBlob = c.blobDev;
+        const size_t cap = std::max<size_t>(total ? total : 16, moved ? c.blobCapacity : 0);
         c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{};
-        API_HIP(&c, hipMalloc(&c.blobDev, total ? total : 16));
-        c.blobCapacity = total ? total : 16;
+        hipError_t ea = hipMalloc(&c.blobDev, cap);
+        if (ea != hipSuccess) { c.blobDev = oldBlob; return fail_hip(&c, ea, "hipMalloc(traversal copy)"); }   // (the adopted pieces stay where they were)
+        c.blobCapacity = cap;
     }
     if (!c.tlasHeaderHost) {
         API_HIP(&c, hipHostMalloc((void**)&c.tlasHeaderHost, sizeof(WideHeader)));
@@ -419,20 +471,44 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     }
     uint8_t* blob = (uint8_t*)c.blobDev;
 
-    // ---- one upload: instance sources | bottom-level table | copy jobs
-    std::vector<BlobCopy> jobs;
-    const size_t tableOff = (srcBytes + 15) / 16 * 16, tableBytes = sizeof(BlasEntry) * table.size();
-    for (const BlasEntry& e : table) {
-        jobs.push_back(BlobCopy{ e.nodes, blob + instBytes + sizeof(WideNode) * (size_t)e.nodeBase, sizeof(WideNode) * (size_t)e.nodeCount / 16 });
-        if (e.triCount) jobs.push_back(BlobCopy{ e.tris, blob + instBytes + nodeBytes + sizeof(TriPacket) * (size_t)e.triBase, sizeof(TriPacket) * (size_t)e.triCount / 16 });
-        if (e.triCount) jobs.push_back(BlobCopy{ e.idx, blob + instBytes + nodeBytes + triBytes + instBytes + instBytes + 16 * (size_t)e.triBase, (uint64_t)e.triCount });
+    // ---- one upload: instance sources | bottom-level table | copy jobs (first the moves / adoptions of static pieces, which run before
+    // anything reads the table; then the per-build copies of updatable pieces and of the top level's nodes, inside the assembly launch)
+    std::vector<BlobCopy> preJobs, jobs;
+    std::vector<Piece*> adopting;
+    for (Piece& p : pieces) {
+        Blas& b = *p.b;
+        uint8_t* dn = blob + node_at(p); uint8_t* dt = blob + tri_at(p); uint8_t* di = blob + idx_at(p);
+        const uint64_t n16 = sizeof(WideNode) * (uint64_t)b.nodeCount / 16, t16 = sizeof(TriPacket) * (uint64_t)b.triCount / 16, i16 = b.triCount;
+        const void *sn, *st_, *si;
+        if (b.updatable) {                                         // own arrays stay the truth: copied in by the assembly launch, read in place by the build's kernels
+            jobs.push_back(BlobCopy{ b.nodes, dn, n16 });
+            if (b.triCount) { jobs.push_back(BlobCopy{ b.tris, dt, t16 }); jobs.push_back(BlobCopy{ b.idx, di, i16 }); }
+            sn = b.nodes; st_ = b.tris; si = b.idx;
+        } else {
+            if (b.inBlob) {
+                if (newBlob) {                                     // moves over from the old copy
+                    const uint8_t* ob = (const uint8_t*)oldBlob;
+                    preJobs.push_back(BlobCopy{ ob + b.blobNodeAt, dn, n16 });
+                    if (b.triCount) { preJobs.push_back(BlobCopy{ ob + b.blobTriAt, dt, t16 }); preJobs.push_back(BlobCopy{ ob + b.blobIdxAt, di, i16 }); }
+                }                                                  // else: in place already
+            } else {                                               // first top level that sees it: adopted
+                preJobs.push_back(BlobCopy{ b.nodes, dn, n16 });
+                if (b.triCount) { preJobs.push_back(BlobCopy{ b.tris, dt, t16 }); preJobs.push_back(BlobCopy{ b.idx, di, i16 }); }
+                adopting.push_back(&p);
+            }
+            sn = dn; st_ = dt; si = di;
+        }
+        if (p.referenced) { BlasEntry& row = table[pieceOf[p.id]]; row.nodes = (const WideNode*)sn; row.tris = (const TriPacket*)st_; row.idx = (const uint4*)si; }
     }
+    const size_t tableOff = (srcBytes + 15) / 16 * 16, tableBytes = sizeof(BlasEntry) * table.size();
     hipError_t e = build_tlas_prepare(c.tlas, count);          // node / order arrays of the TLAS (grow-only), known before the jobs that copy them
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
-    jobs.push_back(BlobCopy{ c.tlas.nodes, blob + instBytes, sizeof(WideNode) * (size_t)tlasNodeCap / 16 });
-    const size_t jobsOff = (tableOff + tableBytes + 15) / 16 * 16, jobsBytes = sizeof(BlobCopy) * jobs.size();
+    jobs.push_back(BlobCopy{ c.tlas.nodes, blob + nodeAt, sizeof(WideNode) * (size_t)tlasNodeExact / 16 });
+    const size_t preOff = (tableOff + tableBytes + 15) / 16 * 16, preBytes = sizeof(BlobCopy) * preJobs.size();
+    const size_t jobsOff = (preOff + preBytes + 15) / 16 * 16, jobsBytes = sizeof(BlobCopy) * jobs.size();
     up.resize(jobsOff + jobsBytes);
     if (tableBytes) memcpy(up.data() + tableOff, table.data(), tableBytes);
+    if (preBytes) memcpy(up.data() + preOff, preJobs.data(), preBytes);
     memcpy(up.data() + jobsOff, jobs.data(), jobsBytes);
     if (up.size() > c.tlasUploadCap || !c.tlasUploadDev) {
         if (!growth) API_HIP(&c, hipStreamSynchronize(c.stream));
@@ -460,22 +536,41 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     const BlasEntry* dTable = (const BlasEntry*)((const uint8_t*)c.tlasUploadDev + tableOff);
     c.blasTableDev = dTable; c.blasTableCount = (uint32_t)table.size(); c.instSourceDev = dSrc; c.blasTableMaxTris = 0;
     for (const BlasEntry& te : table) c.blasTableMaxTris = std::max(c.blasTableMaxTris, te.triCount);
+    const BlobCopy* dPre = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + preOff);
     const BlobCopy* dJobs = (const BlobCopy*)((const uint8_t*)c.tlasUploadDev + jobsOff);
 
     // ---- device side, all in stream order
-    e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.tlas.tree.bounds, c.stream);
+    e = hipSuccess;
+    if (!preJobs.empty()) e = launch_blob_assembly(nullptr, c.tlas, nullptr, 0, nullptr, nullptr, dPre, (uint32_t)preJobs.size(), nullptr, c.stream);   // static pieces into place first: the table points there
+    if (e == hipSuccess) e = launch_instance_records(dSrc, dTable, count, c.tlas.instances, c.tlas.blasBounds, c.tlas.tree.bounds, c.stream);
     if (e == hipSuccess) e = build_tlas_device(c.tlas.instances, c.tlas.blasBounds, count, c.stream, c.tlas);
-    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas, dTable, count, (InstanceT*)blob, (InstanceT*)(blob + instBytes + nodeBytes + triBytes),
-                                                 dJobs, (uint32_t)jobs.size(), (f4v*)(blob + instBytes + nodeBytes + triBytes + instBytes), c.stream);
+    if (e == hipSuccess) e = launch_blob_assembly(c.tlas.instances, c.tlas, dTable, count, (InstanceT*)(blob + instAt), (InstanceT*)(blob + leafAt),
+                                                 dJobs, (uint32_t)jobs.size(), (f4v*)(blob + enterAt), c.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c.tlasHeaderHost, c.tlas.tree.header, sizeof(WideHeader), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipEventRecord(c.tlasHeaderEvent, c.stream);
+    // adoption and moves are load-time events (the first top level of a scene, a change of its meshes): wait for the copies, then let go of
+    // what they read. A frame of a dynamic scene over an unchanged set of meshes comes past here with nothing to do.
+    if (!adopting.empty() || oldBlob) {
+        const hipError_t es = hipStreamSynchronize(c.stream);
+        if (e == hipSuccess) e = es;
+        if (es == hipSuccess) {
+            for (Piece* p : adopting) {
+                Blas& b = *p->b;
+                if (b.nodes) hipFree(b.nodes);
+                if (b.tris) hipFree(b.tris);
+                if (b.idx) hipFree(b.idx);
+                b.nodes = nullptr; b.tris = nullptr; b.idx = nullptr; b.inBlob = true;
+            }
+            if (oldBlob) hipFree(oldBlob);
+        }
+    }
+    for (Piece& p : pieces) if (p.b->inBlob) { p.b->blobNodeAt = node_at(p); p.b->blobTriAt = tri_at(p); p.b->blobIdxAt = idx_at(p); }
     if (e != hipSuccess) return fail_hip(&c, e, "top-level build");
     c.tlasHeaderPending = true;
+    c.tlasNodeReserve = tlasNodeCap;
     c.blob.base = (const f4v*)blob;
-    c.blob.instOff16 = 0; c.blob.nodeOff16 = (uint32_t)(instBytes / 16); c.blob.triOff16 = (uint32_t)((instBytes + nodeBytes) / 16);
-    c.blob.leafInstOff16 = (uint32_t)((instBytes + nodeBytes + triBytes) / 16);
-    c.blob.enterOff16 = (uint32_t)((instBytes + nodeBytes + triBytes + instBytes) / 16);
-    c.blob.idxOff16 = (uint32_t)((instBytes + nodeBytes + triBytes + instBytes + instBytes) / 16);
+    c.blob.nodeOff16 = (uint32_t)(nodeAt / 16); c.blob.triOff16 = (uint32_t)(triAt / 16); c.blob.idxOff16 = (uint32_t)(idxAt / 16);
+    c.blob.instOff16 = (uint32_t)(instAt / 16); c.blob.leafInstOff16 = (uint32_t)(leafAt / 16); c.blob.enterOff16 = (uint32_t)(enterAt / 16);
     c.blob.instCount = count; c.blob.nodeCount = blobNodes; c.blob.triCount = blobTris; c.blob.bytes = (uint32_t)total;
     c.tlas.triangleCount = tris;
     c.tlasBlasIds = pieceIds;
@@ -502,7 +597,7 @@ int pt_share_scene(PtContext* ctx, PtContext* source)
     if (st != PT_OK) return fail(&c, st, s.lastError);
     if (!s.haveTlas) return fail(&c, PT_ERROR_NOT_READY, "the source context has no top-level acceleration structure");
     if (c.sceneOwner) detach_from_owner(c);
-    else { free_tlas(c.tlas); if (c.blobDev) hipFree(c.blobDev); }
+    else { API_HIP(&c, materialise_adopted(c)); free_tlas(c.tlas); if (c.blobDev) hipFree(c.blobDev); }
     c.blobDev = nullptr; c.blobCapacity = 0;
     c.tlas = Tlas();
     c.tlas.instances = s.tlas.instances; c.tlas.instanceCount = s.tlas.instanceCount; c.tlas.triangleCount = s.tlas.triangleCount;   // views
@@ -539,6 +634,7 @@ int pt_get_accel_stats(PtContext* ctx, PtAccelStats* out)
     out->RoundRecordsInLds = round_records_in_lds(c, c.objectCount, c.shadeGeomDev != nullptr);
     if (c.tlasHeaderHost && !c.tlasHeaderPending) out->TopLevelDepth = c.tlasHeaderHost->depth;
     out->NodeBytes = nb; out->TriangleBytes = tb;
+    for (auto& kv : c.blas) if (!kv.second.inBlob) out->OwnedBottomLevelBytes += (uint64_t)kv.second.nodeCount * sizeof(WideNode) + (uint64_t)kv.second.triCount * (sizeof(TriPacket) + 16);
     return PT_OK;
 }
 

@@ -41,6 +41,9 @@ struct Blas {
     float* rootBounds = nullptr;             // device: lo.xyz hi.xyz
     uint32_t triCount = 0, leafCount = 0, nodeCount = 0, depth = 0, geometryCount = 0;
     bool buildError = false, updatable = false;
+    // a static bottom level lives in the context's traversal copy only, once a top-level build has seen it (pt_api.hip pt_build_top_level):
+    // nodes / tris / idx above are null then, and these are the byte offsets of its three pieces in that copy
+    bool inBlob = false; uint64_t blobNodeAt = 0, blobTriAt = 0, blobIdxAt = 0;
     TreeBuffers tree;                        // kept only when updatable
 };
 
@@ -133,7 +136,7 @@ struct Context {
     struct UploadStage { void* host = nullptr; size_t capacity = 0; hipEvent_t event = nullptr; };  // pinned staging of that upload, two in turn
     UploadStage tlasStage[2]; uint32_t tlasStageNext = 0;
     WideHeader* tlasHeaderHost = nullptr; hipEvent_t tlasHeaderEvent = nullptr; bool tlasHeaderPending = false;   // lazy depth / error check
-    uint32_t maxBlasDepth = 0, tlasInstanceCap = 0;
+    uint32_t maxBlasDepth = 0, tlasInstanceCap = 0, tlasNodeReserve = 0;   // tlasNodeReserve: top-level nodes reserved at the head of the traversal copy by the last build
     size_t blobCapacity = 0;
     uint32_t tlasValidatedCount = ~0u, persistentGrid = 0;
     uint64_t tlasBindingHash = 0;                     // over (InstanceID, bottom-level id) of the instances, in order: what the shared-geometry check depends on

@@ -80,7 +80,7 @@ class AccelStats(C.Structure):
                 ("NodeBytes", C.c_uint64), ("TriangleBytes", C.c_uint64), ("NodeSizeBytes", C.c_uint32),
                 ("TriangleSizeBytes", C.c_uint32), ("MaxBottomLevelDepth", C.c_uint32), ("TopLevelDepth", C.c_uint32),
                 ("BlobBytes", C.c_uint64), ("SharedScene", C.c_uint32), ("NormalRecords", C.c_uint32),
-                ("RoundObjectsInLds", C.c_uint32), ("RoundRecordsInLds", C.c_uint32)]
+                ("OwnedBottomLevelBytes", C.c_uint64), ("RoundObjectsInLds", C.c_uint32), ("RoundRecordsInLds", C.c_uint32)]
 
 
 def load_library():

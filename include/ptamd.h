@@ -266,6 +266,8 @@ typedef struct PtAccelStats {
     uint32_t SharedScene;                 /* 1: this context views another context's scene (pt_share_scene) */
     uint32_t NormalRecords;               /* 1: hits take their vertex normals from the frame's normal records (every instance of a bottom level names the same
                                              vertex data; decided when the object data is resolved), 0: fetched through the hit's own object */
+    uint64_t OwnedBottomLevelBytes;       /* nodes + packets + indices of bottom levels held OUTSIDE the traversal copy: updatable ones, and static ones no top level has
+                                             seen yet. A static bottom level lives in the copy only (BlobBytes) once a top-level build has adopted it */
     uint32_t RoundObjectsInLds, RoundRecordsInLds;   /* what the fused round kernel stages in LDS behind the traversal copy: objects (resolved geometry + material) |
                                                         normal records; 0 = none: a hit's shading then fetches them from memory (measurement: which bytes reach HBM) */
 } PtAccelStats;

@@ -860,6 +860,66 @@ def test_release_of_a_referenced_bottom_level_drops_the_top_level(ptamd, pkg):
         ctx.close()
 
 
+def test_static_bottom_levels_live_in_the_traversal_copy_only(ptamd, oracle, pkg):
+    """nodes, packets and indices of a static bottom level used to exist twice -- in the arrays its build left and in the
+    traversal copy every top-level build assembled from them. The first top-level build that sees a static bottom level now ADOPTS it: copies it
+    in, frees the arrays (PtAccelStats.OwnedBottomLevelBytes: what is held outside the copy); later builds find it in place; a change of the
+    layout moves the pieces from the old copy to a new one; adopted bottom levels a top level does not name ride along, so that a later one can
+    name them again; an updatable bottom level keeps its arrays (the refit writes them)."""
+    S, L = pkg.scenes, pkg.layouts
+    W, H = 160, 90
+    gs = S.graphics_settings(W, H, spp=2, bounces=4)
+    ctx = ptamd.DeviceContext(0)
+    try:
+        a = S.sponza_scale(n_side=40, aspect=W / H)
+        a.scene_data = S.make_scene_data((0.2, 0.3, 0.4, 1.0))
+        ga = ptamd.Scene(ctx, a)
+        st = ctx.accel_stats()
+        assert st.OwnedBottomLevelBytes == 0 and st.BlobBytes >= st.NodeBytes + st.TriangleBytes
+        ra = ptamd.Renderer(ctx, ga, W, H, with_f32=True)
+        ra.render(gs); ctx.sync()
+        first = ptamd.textures_to_numpy(ra.textures)
+        ref_gb, ref_rays, ref_f32 = oracle.render(a, gs, accel_mode=1, want_f32=True, layouts=L)
+        assert np.array_equal(first["RadianceF32"].view(np.uint32), ref_f32.view(np.uint32))
+        ga._build_top_level()                                   # the same top level again: everything is in place, nothing moves
+        assert ctx.accel_stats().OwnedBottomLevelBytes == 0
+        ra.render(gs); ctx.sync()
+        assert np.array_equal(ptamd.textures_to_numpy(ra.textures)["RadianceF32"], first["RadianceF32"])
+        # a second scene on the same context: its top level names other bottom levels; the first scene's ride along in the copy ...
+        b = S.instanced_grid(n=6, aspect=W / H)
+        b.scene_data = S.make_scene_data((0.3, 0.3, 0.35, 1.0))
+        gb = ptamd.Scene(ctx, b)
+        assert ctx.accel_stats().OwnedBottomLevelBytes == 0
+        rb = ptamd.Renderer(ctx, gb, W, H, with_f32=True)
+        rb.render(gs); ctx.sync()
+        refb_gb, refb_rays, refb_f32 = oracle.render(b, gs, accel_mode=1, want_f32=True, layouts=L)
+        assert np.array_equal(ptamd.textures_to_numpy(rb.textures)["RadianceF32"].view(np.uint32), refb_f32.view(np.uint32))
+        # ... so the first scene's top level can be built again (another layout: its pieces move) and renders the same frame
+        import ctypes as C
+        ctx.check(ctx.lib.pt_heap_resize(ctx.handle, len(a.heap)))                 # (the second scene had bound its own descriptor table and object data)
+        for i, (item, t) in enumerate(zip(a.heap, ga._heap_dev)):
+            ctx.check(ctx.lib.pt_heap_set_buffer(ctx.handle, i, C.c_void_p(t.data_ptr()), item.array.nbytes, item.stride))
+        ctx.check(ctx.lib.pt_set_object_data(ctx.handle, ga.object_data.data_ptr(), len(a.object_data)))
+        ctx.check(ctx.lib.pt_set_instance_data(ctx.handle, ga.instance_data.data_ptr(), len(a.instance_data)))
+        ga._build_top_level()
+        ra.render(gs); ctx.sync()
+        assert np.array_equal(ptamd.textures_to_numpy(ra.textures)["RadianceF32"], first["RadianceF32"])
+        gb.close(); ga.close()
+        # a dynamic scene: the skinned mesh's bottom level keeps its arrays, the static ones do not
+        d = S.dynamic_scene(aspect=W / H)
+        gd = ptamd.Scene(ctx, d)
+        owned = ctx.accel_stats().OwnedBottomLevelBytes
+        bar = d.nodes[2].meshes[0]
+        assert 0 < owned <= (bar.indices.size // 3) * (48 + 16 + 80)
+        for k in range(3):
+            gd.SkinSkeletalMeshes(bar, S.bar_pose(10.0 * k, 0.02 * k))
+            gd.UpdateAccelerationStructures(2)
+        assert ctx.accel_stats().OwnedBottomLevelBytes == owned
+        gd.close()
+    finally:
+        ctx.close()
+
+
 def test_scene_inputs_are_validated(ptamd, pkg):
     """indices the kernels dereference are checked once per scene change, with a message naming the culprit."""
     import torch
