@@ -459,10 +459,10 @@ int pt_build_top_level(PtContext* ctx, const PtInstanceDesc* descs, uint32_t cou
     void* oldBlob = nullptr;                                       // pieces move over from it; freed once the moves have run
     if (newBlob) {
         oldBlob = c.blobDev;
-        const size_t cap = std::max<size_t>(total ? total : 16, moved ? c.blobCapacity : 0);
+        const size_t oldCap = c.blobCapacity, cap = std::max<size_t>(total ? total : 16, moved ? c.blobCapacity : 0);
         c.blobDev = nullptr; c.blobCapacity = 0; c.blob = BlobView{};
         hipError_t ea = hipMalloc(&c.blobDev, cap);
-        if (ea != hipSuccess) { c.blobDev = oldBlob; return fail_hip(&c, ea, "hipMalloc(traversal copy)"); }   // (the adopted pieces stay where they were)
+        if (ea != hipSuccess) { c.blobDev = oldBlob; c.blobCapacity = oldCap; return fail_hip(&c, ea, "hipMalloc(traversal copy)"); }   // (the adopted pieces stay where they were)
         c.blobCapacity = cap;
     }
     if (!c.tlasHeaderHost) {

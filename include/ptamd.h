@@ -401,10 +401,10 @@ int  pt_set_debug_flags(PtContext* ctx, uint32_t flags);
 /* first mismatching ray under PT_DEBUG_BRUTE_FORCE: o.xyz tmin d.xyz tmax | bvh inst slot t - | brute inst slot t - */
 int  pt_debug_read_mismatch(PtContext* ctx, float* out16);
 
-/* Developer / test aid: the traversal copy of the scene (instances, 8-wide nodes of the top level and of every referenced
- * bottom level, triangle packets in node order, the instance records again in top-level leaf order, then -- after LeafInstanceOffset16 + 9 units per instance --
- * the entry records of the streaming traversal: transform, bases and a copy of the bottom level's root node) copied to host memory, with its
- * section offsets in 16-byte units. tests/ decode it to check the structural invariants of the builder (containment, reference ranges, depth). Synchronises. */
+/* Developer / test aid: the traversal copy of the scene (8-wide nodes of the top level and of every bottom level, triangle packets in node order,
+ * their vertex indices, the instance records in API order and again in top-level leaf order, then -- after LeafInstanceOffset16 + 9 units per
+ * instance -- the entry records of the streaming traversal: transform, bases and a copy of the bottom level's root node) copied to host memory,
+ * with its section offsets in 16-byte units. tests/ decode it to check the structural invariants of the builder (containment, reference ranges, depth). Synchronises. */
 typedef struct PtBlobLayout {
     uint32_t InstanceOffset16, NodeOffset16, TriangleOffset16, LeafInstanceOffset16;
     uint32_t InstanceCount, NodeCount, TriangleCount, Bytes;
