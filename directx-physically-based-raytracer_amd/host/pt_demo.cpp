@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "ptamd.hpp"
+#include "pt_ingest.hpp"
 
 using namespace ptamd;
 
@@ -111,6 +112,138 @@ template <typename T> static T* upload(const std::vector<T>& v)
     return d;
 }
 
+// What the host hands the library, whichever way it came about (built in code below, or loaded by pt_ingest.hpp): mesh nodes (one bottom level
+// each, one geometry per mesh), instances of them, a camera and the environment.
+struct HostGeometry { std::vector<uint8_t> vertices; uint32_t vertexCount = 0; std::vector<uint8_t> indices; uint32_t indexCount = 0, indexStride = 2;
+                      bool hasNormals = true, hasTangents = false, hasUV[2] = { false, false }; PtMaterial material{}; };
+struct HostNode { std::vector<HostGeometry> meshes; };
+struct HostObject { uint32_t node = 0; float transform[12]; bool visible = true; };
+struct HostScene {
+    std::vector<HostNode> nodes; std::vector<HostObject> objects;
+    double cameraPosition[3] = { 0, 0, 0 }, cameraForward[3] = { 0, 0, 1 }, cameraUp[3] = { 0, 1, 0 };
+    float envColor[4] = { 0, 0, 0, 1 }, envTransform[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+};
+
+static HostGeometry to_geometry(const HostMesh& m)
+{
+    HostGeometry g;
+    g.vertexCount = (uint32_t)m.vertices.size(); g.vertices.resize(m.vertices.size() * sizeof(Vertex)); memcpy(g.vertices.data(), m.vertices.data(), g.vertices.size());
+    g.indexCount = (uint32_t)m.indices.size(); g.indices.resize(m.indices.size() * 2); memcpy(g.indices.data(), m.indices.data(), g.indices.size());
+    g.material = m.material;
+    return g;
+}
+
+// scenes.py:cornell_box, variant "ggx": one mesh node per object, camera at the front opening looking +Z
+static HostScene cornell_scene()
+{
+    HostScene sc;
+    const PtMaterial white = make_material(0.73f, 0.73f, 0.73f), red = make_material(0.65f, 0.05f, 0.05f), green = make_material(0.12f, 0.45f, 0.15f);
+    const double floorP[4][3] = { { -1, -1, -1 }, { -1, -1, 1 }, { 1, -1, 1 }, { 1, -1, -1 } }, up[3] = { 0, 1, 0 };
+    const double ceilP[4][3] = { { -1, 1, -1 }, { 1, 1, -1 }, { 1, 1, 1 }, { -1, 1, 1 } }, down[3] = { 0, -1, 0 };
+    const double backP[4][3] = { { -1, -1, 1 }, { -1, 1, 1 }, { 1, 1, 1 }, { 1, -1, 1 } }, toCam[3] = { 0, 0, -1 };
+    const double leftP[4][3] = { { -1, -1, -1 }, { -1, 1, -1 }, { -1, 1, 1 }, { -1, -1, 1 } }, px[3] = { 1, 0, 0 };
+    const double rightP[4][3] = { { 1, -1, -1 }, { 1, -1, 1 }, { 1, 1, 1 }, { 1, 1, -1 } }, nx[3] = { -1, 0, 0 };
+    const double lightP[4][3] = { { -0.25, 0, -0.25 }, { 0.25, 0, -0.25 }, { 0.25, 0, 0.25 }, { -0.25, 0, 0.25 } };
+    const std::vector<HostMesh> meshes = {
+        quad(floorP, up, white), quad(ceilP, down, white), quad(backP, toCam, white), quad(leftP, px, red), quad(rightP, nx, green),
+        quad(lightP, down, make_material(0.78f, 0.78f, 0.78f, 1, 1, 1, 15.0f)),
+        box(make_material(0.95f, 0.93f, 0.88f, 0, 0, 0, 1, 1.0f, 0.05f)), box(make_material(0.73f, 0.73f, 0.73f, 0, 0, 0, 1, 0, 0.2f)) };
+    float xf[8][12];
+    for (int i = 0; i < 5; i++) trs(xf[i], 0, 0, 0, 0, 1, 1, 1);
+    trs(xf[5], 0, 0.998, 0.1, 0, 1, 1, 1);
+    trs(xf[6], -0.35, -0.4, 0.35, -18.0, 0.6, 1.2, 0.6);
+    trs(xf[7], 0.35, -0.7, -0.25, 15.0, 0.6, 0.6, 0.6);
+    for (size_t i = 0; i < meshes.size(); i++) {
+        HostNode n; n.meshes.push_back(to_geometry(meshes[i])); sc.nodes.push_back(std::move(n));
+        HostObject o; o.node = (uint32_t)i; memcpy(o.transform, xf[i], 48); sc.objects.push_back(o);
+    }
+    sc.cameraPosition[2] = -1.95;
+    return sc;
+}
+
+// a scene descriptor in the reference's schema (Source/MyScene.ixx:33-90) with its glTF models, through host/pt_ingest.hpp.
+// Camera: App::ResetCamera = CameraController::SetPosition / SetRotation (Source/Camera.ixx:84-97), default lens.
+static HostScene ingested_scene(const std::string& path)
+{
+    const ingest::Scene in = ingest::load_scene(path);
+    HostScene sc;
+    for (auto& node : in.Nodes) {
+        HostNode n;
+        for (const ingest::MeshData& md : node->Meshes) {
+            HostGeometry g;
+            g.vertexCount = (uint32_t)md.Vertices.size(); g.vertices.resize(md.Vertices.size() * sizeof(ingest::Vertex)); memcpy(g.vertices.data(), md.Vertices.data(), g.vertices.size());
+            g.indices = md.Indices; g.indexCount = md.IndexCount; g.indexStride = md.IndexStride;
+            g.hasNormals = md.HasNormals; g.hasTangents = md.HasTangents; g.hasUV[0] = md.HasUV[0]; g.hasUV[1] = md.HasUV[1];
+            g.material = md.HasMaterial ? md.Material : ingest::default_material();            // App.cpp:1044: Material() when a mesh names none
+            for (const std::string& slot : md.SkippedTextures) fprintf(stderr, "pt_demo: %s texture of a material not loaded (no image codec in this host)\n", slot.c_str());
+            n.meshes.push_back(std::move(g));
+        }
+        sc.nodes.push_back(std::move(n));
+    }
+    for (const ingest::RenderObject& ro : in.Objects) { HostObject o; o.node = ro.Node; memcpy(o.transform, ro.Transform, 48); o.visible = ro.IsVisible; sc.objects.push_back(o); }
+    const ingest::M4& r = in.CameraRotation;                         // forward = (0,0,1,0) R, right = (1,0,0,0) R, up = forward x right (ingest.py camera_from_desc)
+    const double fwd[3] = { r.m[2][0], r.m[2][1], r.m[2][2] }, right[3] = { r.m[0][0], r.m[0][1], r.m[0][2] };
+    for (int k = 0; k < 3; k++) { sc.cameraPosition[k] = in.CameraPosition[k]; sc.cameraForward[k] = fwd[k]; }
+    sc.cameraUp[0] = fwd[1] * right[2] - fwd[2] * right[1]; sc.cameraUp[1] = fwd[2] * right[0] - fwd[0] * right[2]; sc.cameraUp[2] = fwd[0] * right[1] - fwd[1] * right[0];
+    memcpy(sc.envColor, in.EnvironmentLightColor, 16); memcpy(sc.envTransform, in.EnvironmentLightTransform, 48);
+    return sc;
+}
+
+// scenes.py:make_camera (hfov 90, near 0.01, far inf): XMMatrixLookToLH + SetupByHalfFovxInf, row-vector convention
+static PtCamera make_camera(const HostScene& sc, double aspect)
+{
+    auto norm = [](double v[3]) { const double l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; };
+    auto cross = [](const double a[3], const double b[3], double o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    double f[3] = { sc.cameraForward[0], sc.cameraForward[1], sc.cameraForward[2] }, r[3], u[3];
+    norm(f); cross(sc.cameraUp, f, r); norm(r); cross(f, r, u);
+    const double* pos = sc.cameraPosition;
+    const double rightLen = std::tan((90.0 * (M_PI / 180.0)) / 2), upLen = rightLen / aspect, nearD = 0.01;
+    PtCamera cam{};
+    cam.IsNormalizedDepthReversed = 1;
+    for (int k = 0; k < 3; k++) {
+        cam.Position[k] = cam.PreviousPosition[k] = (float)pos[k];
+        cam.RightDirection[k] = (float)(r[k] * rightLen); cam.UpDirection[k] = (float)(u[k] * upLen); cam.ForwardDirection[k] = (float)f[k];
+    }
+    cam.NearDepth = (float)nearD; cam.FarDepth = std::numeric_limits<float>::infinity();
+    double w2v[4][4] = {}, v2p[4][4] = {}, w2p[4][4] = {};
+    for (int k = 0; k < 3; k++) { w2v[k][0] = r[k]; w2v[k][1] = u[k]; w2v[k][2] = f[k]; }
+    w2v[3][0] = -dot(pos, r); w2v[3][1] = -dot(pos, u); w2v[3][2] = -dot(pos, f); w2v[3][3] = 1;
+    v2p[0][0] = 1 / rightLen; v2p[1][1] = aspect / rightLen; v2p[2][3] = 1; v2p[3][2] = nearD;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) w2p[i][j] += w2v[i][k] * v2p[k][j];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        cam.WorldToProjection[4 * i + j] = cam.PreviousWorldToProjection[4 * i + j] = (float)w2p[i][j];
+        cam.PreviousWorldToView[4 * i + j] = (float)w2v[i][j]; cam.PreviousViewToProjection[4 * i + j] = (float)v2p[i][j];
+    }
+    return cam;
+}
+
+// --dump-scene: what would be handed to the library, byte for byte, without touching a GPU (tests/test_host_cpp.py compares it with the harness's ingest)
+static int dump_scene(const HostScene& sc, const std::string& path)
+{
+    FILE* fp = fopen(path.c_str(), "wb");
+    if (!fp) { fprintf(stderr, "cannot open %s\n", path.c_str()); return 3; }
+    printf("{\"nodes\": [");
+    for (size_t n = 0; n < sc.nodes.size(); n++) {
+        printf("%s[", n ? ", " : "");
+        for (size_t m = 0; m < sc.nodes[n].meshes.size(); m++) {
+            const HostGeometry& g = sc.nodes[n].meshes[m];
+            printf("%s{\"vertices\": %u, \"indices\": %u, \"index_stride\": %u, \"has_normals\": %d, \"has_tangents\": %d, \"has_uv\": [%d, %d]}", m ? ", " : "",
+                   g.vertexCount, g.indexCount, g.indexStride, g.hasNormals, g.hasTangents, g.hasUV[0], g.hasUV[1]);
+            fwrite(g.vertices.data(), 1, g.vertices.size(), fp); fwrite(g.indices.data(), 1, g.indices.size(), fp); fwrite(&g.material, sizeof(PtMaterial), 1, fp);
+        }
+        printf("]");
+    }
+    printf("], \"objects\": [");
+    for (size_t i = 0; i < sc.objects.size(); i++) { printf("%s{\"node\": %u, \"visible\": %d}", i ? ", " : "", sc.objects[i].node, sc.objects[i].visible ? 1 : 0); fwrite(sc.objects[i].transform, 4, 12, fp); }
+    printf("]}\n");
+    fwrite(sc.envColor, 4, 4, fp); fwrite(sc.envTransform, 4, 12, fp);
+    const PtCamera cam = make_camera(sc, 16.0 / 9.0);
+    fwrite(&cam, sizeof cam, 1, fp);
+    fclose(fp);
+    return 0;
+}
+
 // --ranks R: start one child per rank and wait for them (no GPU call has been made in this process, and none will be).
 // The unique id travels through a file in a directory of our own (mkdtemp: mode 0700, unpredictable name). The first rank that fails
 // ends the run: the others would wait for it inside ncclCommInitRank or a grouped receive for ever, so they are killed.
@@ -180,7 +313,7 @@ static std::vector<uint8_t> exchange_unique_id(uint32_t rank, const std::string&
 int main(int argc, char** argv)
 {
     uint32_t W = 1920, H = 1080, spp = 4, bounces = 8, frames = 10, ranks = 0, rank = 0, world = 1;
-    std::string out, idFile;
+    std::string out, idFile, scenePath, dumpPath;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--width") W = atoi(argv[i + 1]); else if (k == "--height") H = atoi(argv[i + 1]);
@@ -188,8 +321,13 @@ int main(int argc, char** argv)
         else if (k == "--frames") frames = atoi(argv[i + 1]); else if (k == "--out") out = argv[i + 1];
         else if (k == "--ranks") ranks = atoi(argv[i + 1]); else if (k == "--rank") rank = atoi(argv[i + 1]);
         else if (k == "--world") world = atoi(argv[i + 1]); else if (k == "--id-file") idFile = argv[i + 1];
+        else if (k == "--scene") scenePath = argv[i + 1]; else if (k == "--dump-scene") dumpPath = argv[i + 1];
     }
     const bool sharded = !idFile.empty();
+    if (!dumpPath.empty()) {                                        // no GPU call on this path
+        try { return dump_scene(scenePath.empty() ? cornell_scene() : ingested_scene(scenePath), dumpPath); }
+        catch (const std::exception& e) { fprintf(stderr, "pt_demo: %s\n", e.what()); return 1; }
+    }
     if (ranks && !sharded) return launch_ranks(argc, argv, ranks);
     try {
         int deviceCount = 0;
@@ -202,70 +340,63 @@ int main(int argc, char** argv)
         if (sharded) sharding.Join(commandList, rank, world, exchange_unique_id(rank, idFile).data());
         const uint32_t localRows = sharding.LocalRows(H);
 
-        // ---- scene (scenes.py:cornell_box, variant "ggx")
-        const PtMaterial white = make_material(0.73f, 0.73f, 0.73f), red = make_material(0.65f, 0.05f, 0.05f), green = make_material(0.12f, 0.45f, 0.15f);
-        const double floorP[4][3] = { { -1, -1, -1 }, { -1, -1, 1 }, { 1, -1, 1 }, { 1, -1, -1 } }, up[3] = { 0, 1, 0 };
-        const double ceilP[4][3] = { { -1, 1, -1 }, { 1, 1, -1 }, { 1, 1, 1 }, { -1, 1, 1 } }, down[3] = { 0, -1, 0 };
-        const double backP[4][3] = { { -1, -1, 1 }, { -1, 1, 1 }, { 1, 1, 1 }, { 1, -1, 1 } }, toCam[3] = { 0, 0, -1 };
-        const double leftP[4][3] = { { -1, -1, -1 }, { -1, 1, -1 }, { -1, 1, 1 }, { -1, -1, 1 } }, px[3] = { 1, 0, 0 };
-        const double rightP[4][3] = { { 1, -1, -1 }, { 1, -1, 1 }, { 1, 1, 1 }, { 1, 1, -1 } }, nx[3] = { -1, 0, 0 };
-        const double lightP[4][3] = { { -0.25, 0, -0.25 }, { 0.25, 0, -0.25 }, { 0.25, 0, 0.25 }, { -0.25, 0, 0.25 } };
-        std::vector<HostMesh> meshes = {
-            quad(floorP, up, white), quad(ceilP, down, white), quad(backP, toCam, white), quad(leftP, px, red), quad(rightP, nx, green),
-            quad(lightP, down, make_material(0.78f, 0.78f, 0.78f, 1, 1, 1, 15.0f)),
-            box(make_material(0.95f, 0.93f, 0.88f, 0, 0, 0, 1, 1.0f, 0.05f)), box(make_material(0.73f, 0.73f, 0.73f, 0, 0, 0, 1, 0, 0.2f)) };
-        float xf[8][12];
-        for (int i = 0; i < 5; i++) trs(xf[i], 0, 0, 0, 0, 1, 1, 1);
-        trs(xf[5], 0, 0.998, 0.1, 0, 1, 1, 1);
-        trs(xf[6], -0.35, -0.4, 0.35, -18.0, 0.6, 1.2, 0.6);
-        trs(xf[7], 0.35, -0.7, -0.25, 15.0, 0.6, 0.6, 0.6);
+        // ---- scene: the Cornell box built in code (scenes.py:cornell_box, variant "ggx"), or --scene <descriptor.json> through pt_ingest.hpp
+        const HostScene scene = scenePath.empty() ? cornell_scene() : ingested_scene(scenePath);
 
-        // ---- buffers, descriptor heap, ObjectData / InstanceData (App::UpdateScene, Source/App.cpp:1028-1074)
-        const uint32_t n = (uint32_t)meshes.size();
-        ThrowIfFailed(commandList.Context, pt_heap_resize(commandList.Context, 2 * n));
-        std::vector<PtObjectData> objectData(n); std::vector<PtInstanceData> instanceData(n);
-        std::vector<uint64_t> blas(n); std::vector<PtInstanceDesc> instanceDescs(n);
-        for (uint32_t i = 0; i < n; i++) {
-            Vertex* dv = upload(meshes[i].vertices); uint16_t* di = upload(meshes[i].indices);
-            ThrowIfFailed(commandList.Context, pt_heap_set_buffer(commandList.Context, 2 * i, dv, meshes[i].vertices.size() * sizeof(Vertex), 0));
-            ThrowIfFailed(commandList.Context, pt_heap_set_buffer(commandList.Context, 2 * i + 1, di, meshes[i].indices.size() * 2, 2));
-            PtObjectData& od = objectData[i]; memset(&od, 0, sizeof od);
-            od.VertexDesc.Stride = sizeof(Vertex);
-            od.VertexDesc.AttributeOffsets.Normal = 12; od.VertexDesc.AttributeOffsets.Tangent = ~0u;
-            od.VertexDesc.AttributeOffsets.TextureCoordinates[0] = od.VertexDesc.AttributeOffsets.TextureCoordinates[1] = ~0u;
-            od.MeshDescriptors.Vertices = 2 * i; od.MeshDescriptors.Indices = 2 * i + 1; od.MeshDescriptors.MotionVectors = ~0u;
-            od.Material = meshes[i].material;
-            for (auto& t : od.TextureMapInfoArray) t.Descriptor = ~0u;
-            PtInstanceData& id = instanceData[i]; memset(&id, 0, sizeof id);
-            id.FirstGeometryIndex = i;
-            memcpy(id.ObjectToWorld, xf[i], 48); memcpy(id.PreviousObjectToWorld, xf[i], 48);
-            // Scene::CreateAccelerationStructures: one BLAS per mesh node, one geometry per mesh
-            const PtGeometryDesc g = RaytracingHelpers::CreateGeometryDesc({ dv, meshes[i].vertices.size(), sizeof(Vertex) }, { di, meshes[i].indices.size(), 2 },
-                                                                           PT_GEOMETRY_FLAG_OPAQUE);
-            blas[i] = RaytracingHelpers::BuildBottomLevelAccelerationStructure(commandList, std::span(&g, 1), PT_BUILD_FLAG_PREFER_FAST_TRACE);
-            PtInstanceDesc& d = instanceDescs[i]; memset(&d, 0, sizeof d);
-            memcpy(d.Transform, xf[i], 48); d.InstanceID = i; d.InstanceMask = ~0u; d.AccelerationStructure = blas[i];
+        // ---- buffers, descriptor heap, bottom levels (Scene::CreateAccelerationStructures: one per mesh node, one geometry per mesh)
+        uint32_t heapSize = 0;
+        for (const HostNode& nd : scene.nodes) heapSize += 2 * (uint32_t)nd.meshes.size();
+        ThrowIfFailed(commandList.Context, pt_heap_resize(commandList.Context, heapSize));
+        struct GeometryOnDevice { uint32_t heapVertices, heapIndices; };
+        std::vector<std::vector<GeometryOnDevice>> onDevice(scene.nodes.size());
+        std::vector<uint64_t> blas(scene.nodes.size());
+        uint32_t heapNext = 0;
+        for (size_t ni = 0; ni < scene.nodes.size(); ni++) {
+            std::vector<PtGeometryDesc> geoms;
+            for (const HostGeometry& hg : scene.nodes[ni].meshes) {
+                uint8_t* dv = upload(hg.vertices); uint8_t* di = upload(hg.indices);
+                ThrowIfFailed(commandList.Context, pt_heap_set_buffer(commandList.Context, heapNext, dv, hg.vertices.size(), 0));
+                ThrowIfFailed(commandList.Context, pt_heap_set_buffer(commandList.Context, heapNext + 1, di, hg.indices.size(), hg.indexStride));
+                onDevice[ni].push_back({ heapNext, heapNext + 1 }); heapNext += 2;
+                // Scene.ixx:320-324: FLAG_OPAQUE unless the material is alpha-tested / blended
+                geoms.push_back(RaytracingHelpers::CreateGeometryDesc({ dv, hg.vertexCount, sizeof(Vertex) }, { di, hg.indexCount, hg.indexStride },
+                                                                      hg.material.AlphaMode == 0 ? PT_GEOMETRY_FLAG_OPAQUE : 0u));
+            }
+            blas[ni] = RaytracingHelpers::BuildBottomLevelAccelerationStructure(commandList, geoms, PT_BUILD_FLAG_PREFER_FAST_TRACE);
         }
+        // ---- ObjectData / InstanceData (App::UpdateScene, Source/App.cpp:1028-1074): one object record per (instance, geometry), InstanceID = the
+        // instance's first object (Scene.ixx:371)
+        std::vector<PtObjectData> objectData; std::vector<PtInstanceData> instanceData(scene.objects.size());
+        std::vector<PtInstanceDesc> instanceDescs(scene.objects.size());
+        for (size_t i = 0; i < scene.objects.size(); i++) {
+            const HostObject& ho = scene.objects[i];
+            const uint32_t first = (uint32_t)objectData.size();
+            for (size_t g = 0; g < scene.nodes[ho.node].meshes.size(); g++) {
+                const HostGeometry& hg = scene.nodes[ho.node].meshes[g];
+                PtObjectData od; memset(&od, 0, sizeof od);
+                od.VertexDesc.Stride = sizeof(Vertex);
+                od.VertexDesc.AttributeOffsets.Normal = hg.hasNormals ? 12u : ~0u; od.VertexDesc.AttributeOffsets.Tangent = hg.hasTangents ? 18u : ~0u;
+                od.VertexDesc.AttributeOffsets.TextureCoordinates[0] = hg.hasUV[0] ? 24u : ~0u; od.VertexDesc.AttributeOffsets.TextureCoordinates[1] = hg.hasUV[1] ? 28u : ~0u;
+                od.MeshDescriptors.Vertices = onDevice[ho.node][g].heapVertices; od.MeshDescriptors.Indices = onDevice[ho.node][g].heapIndices; od.MeshDescriptors.MotionVectors = ~0u;
+                od.Material = hg.material;
+                for (auto& t : od.TextureMapInfoArray) t.Descriptor = ~0u;
+                objectData.push_back(od);
+            }
+            PtInstanceData& id = instanceData[i]; memset(&id, 0, sizeof id);
+            id.FirstGeometryIndex = first;
+            memcpy(id.ObjectToWorld, ho.transform, 48); memcpy(id.PreviousObjectToWorld, ho.transform, 48);
+            PtInstanceDesc& d = instanceDescs[i]; memset(&d, 0, sizeof d);
+            memcpy(d.Transform, ho.transform, 48); d.InstanceID = first; d.InstanceMask = ho.visible ? ~0u : 0u; d.AccelerationStructure = blas[ho.node];
+        }
+        const uint32_t n = (uint32_t)objectData.size(), nInstances = (uint32_t)scene.objects.size();
         RaytracingHelpers::TopLevelAccelerationStructure tlas;
         RaytracingHelpers::BuildTopLevelAccelerationStructure(commandList, PT_BUILD_FLAG_PREFER_FAST_TRACE, instanceDescs, false, tlas);
         PtObjectData* dObjects = upload(objectData); PtInstanceData* dInstances = upload(instanceData);
 
-        // ---- camera (scenes.py:make_camera((0,0,-1.95), hfov 90, near 0.01, far inf)) and scene data
-        PtCamera cam{}; const double aspect = (double)W / (double)H;
-        const double rightLen = std::tan((90.0 * (M_PI / 180.0)) / 2), upLen = rightLen / aspect, nearD = 0.01;
-        cam.IsNormalizedDepthReversed = 1;
-        cam.Position[2] = cam.PreviousPosition[2] = -1.95f;
-        cam.RightDirection[0] = (float)rightLen; cam.UpDirection[1] = (float)upLen; cam.ForwardDirection[2] = 1;
-        cam.NearDepth = (float)nearD; cam.FarDepth = std::numeric_limits<float>::infinity();
-        double w2v[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 1.95, 1 } }, v2p[4][4] = {}, w2p[4][4] = {};
-        v2p[0][0] = 1 / rightLen; v2p[1][1] = aspect / rightLen; v2p[2][3] = 1; v2p[3][2] = nearD;
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) w2p[i][j] += w2v[i][k] * v2p[k][j];
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
-            cam.WorldToProjection[4 * i + j] = cam.PreviousWorldToProjection[4 * i + j] = (float)w2p[i][j];
-            cam.PreviousWorldToView[4 * i + j] = (float)w2v[i][j]; cam.PreviousViewToProjection[4 * i + j] = (float)v2p[i][j];
-        }
-        PtSceneData sd{}; sd.IsStatic = 1; sd.EnvironmentLightTextureDescriptor = ~0u; sd.EnvironmentLightColor[3] = 1;
-        sd.EnvironmentLightTransform[0] = sd.EnvironmentLightTransform[5] = sd.EnvironmentLightTransform[10] = 1;
+        // ---- camera (scenes.py:make_camera: hfov 90, near 0.01, far inf) and scene data
+        PtCamera cam = make_camera(scene, (double)W / (double)H);
+        PtSceneData sd{}; sd.IsStatic = 1; sd.EnvironmentLightTextureDescriptor = ~0u;
+        memcpy(sd.EnvironmentLightColor, scene.envColor, 16); memcpy(sd.EnvironmentLightTransform, scene.envTransform, 48);
 
         // ---- textures (Source/App.cpp:438-455 formats)
         const size_t px_ = (size_t)W * std::max(localRows, 1u), fullPx = (size_t)W * H;     // a rank's textures hold its own rows
@@ -280,7 +411,7 @@ int main(int argc, char** argv)
 
         // ---- App::RenderScene
         GBufferGeneration gbuffer(commandList);
-        gbuffer.GPUBuffers = { &sd, &cam, dInstances, dObjects, n, n };
+        gbuffer.GPUBuffers = { &sd, &cam, dInstances, dObjects, nInstances, n };
         gbuffer.Textures = tx;
         Raytracing raytracing(commandList);
         raytracing.GPUBuffers = { &sd, &cam, dObjects, n };

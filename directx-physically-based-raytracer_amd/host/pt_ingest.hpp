@@ -1,0 +1,517 @@
+// pt_ingest.hpp -- scene-JSON + glTF 2.0 ingest for the C++ host, in the reference's schema and conventions.
+//
+// What it mirrors (host side of the path, upstream of the acceleration-structure build):
+//   scene descriptor   Source/MyScene.ixx:33-90, Source/JSONConverters.ixx:12-33, Source/Scene.ixx:33-73
+//                      {Camera{Position,Rotation}, EnvironmentLight{Color,Rotation,Texture}, Models{name:path},
+//                       RenderObjects[{Name,Transform{Translation,Rotation,Scale},IsVisible,Model}]}
+//   glTF loader        Source/GLTFHelpers.ixx:142-537 (ProcessPrimitive, LoadModel): triangles only, the index array written BACKWARDS
+//                      (flipWindingOrder is always set, Scene.ixx:90), u16 indices iff count <= 65535, tangents ALWAYS recomputed when
+//                      NORMAL + TEXCOORD_0 exist, material factors incl. KHR_materials_emissive_strength / ior / transmission
+//   instance transform Source/Scene.ixx:195-231: world = GlobalTransform * Scale(1,1,-1) * RenderObject.Transform() (row vectors),
+//                      AffineTransform = Scale * Rotation * Translation (Math.ixx:17-19)
+// Same conventions, same arithmetic order as the test harness's ingest.py, so that both hosts hand the library the same bytes
+// (tests/test_host_cpp.py compares vertex / index buffers, transforms and materials of the committed fixture, and the rendered frame).
+// Not here: image codecs. The reference decodes texture files with DirectXTex / stb behind TextureHelpers.ixx; this image has neither, so
+// texture references of a material are listed in MeshData::SkippedTextures and the material keeps its factors (the library takes textures
+// as texel arrays through pt_heap_set_texture: a host with a decoder fills the slots there).
+// [DirectXMesh spec] ComputeTangentFrame is an un-vendored dependency: restated as Lengyel's per-vertex accumulation with Gram-Schmidt
+// against the normal (as in ingest.py). Header-only, C++20, no dependency beyond the standard library and include/ptamd.h.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ptamd.h"
+
+namespace ptamd::ingest {
+
+// ------------------------------------------------------------------------------------------------
+// a small JSON reader (objects, arrays, strings, numbers, true / false / null)
+// ------------------------------------------------------------------------------------------------
+struct Json {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false; double num = 0.0; std::string str;
+    std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+
+    const Json* find(const std::string& key) const
+    {
+        if (kind != Object) return nullptr;
+        for (auto& kv : obj) if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    bool has(const std::string& key) const { const Json* j = find(key); return j && j->kind != Null; }
+    const Json& at(const std::string& key) const { const Json* j = find(key); if (!j) throw std::runtime_error("JSON: missing key " + key); return *j; }
+    const Json& at(size_t i) const { if (kind != Array || i >= arr.size()) throw std::runtime_error("JSON: index out of range"); return arr[i]; }
+    double number(const std::string& key, double def) const { const Json* j = find(key); return j && j->kind == Number ? j->num : def; }
+    size_t size() const { return kind == Array ? arr.size() : obj.size(); }
+};
+
+class JsonParser {
+public:
+    explicit JsonParser(const std::string& text) : s(text) {}
+    Json parse() { Json v = value(); ws(); if (p != s.size()) fail("trailing characters"); return v; }
+
+private:
+    const std::string& s; size_t p = 0;
+    [[noreturn]] void fail(const char* what) const { throw std::runtime_error(std::string("JSON: ") + what + " at byte " + std::to_string(p)); }
+    void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\n' || s[p] == '\t' || s[p] == '\r')) p++; }
+    bool eat(char c) { ws(); if (p < s.size() && s[p] == c) { p++; return true; } return false; }
+    Json value()
+    {
+        ws();
+        if (p >= s.size()) fail("unexpected end");
+        Json v;
+        const char c = s[p];
+        if (c == '{') {
+            p++; v.kind = Json::Object;
+            if (eat('}')) return v;
+            do { ws(); Json k = value(); if (k.kind != Json::String) fail("object key is not a string"); if (!eat(':')) fail("':' expected"); v.obj.emplace_back(k.str, value()); } while (eat(','));
+            if (!eat('}')) fail("'}' expected");
+        } else if (c == '[') {
+            p++; v.kind = Json::Array;
+            if (eat(']')) return v;
+            do v.arr.push_back(value()); while (eat(','));
+            if (!eat(']')) fail("']' expected");
+        } else if (c == '"') {
+            p++; v.kind = Json::String;
+            while (p < s.size() && s[p] != '"') {
+                if (s[p] == '\\') {
+                    if (++p >= s.size()) fail("bad escape");
+                    switch (s[p]) {
+                    case 'n': v.str += '\n'; break; case 't': v.str += '\t'; break; case 'r': v.str += '\r'; break;
+                    case 'b': v.str += '\b'; break; case 'f': v.str += '\f'; break;
+                    case 'u': {                                            // BMP code point -> UTF-8 (names and paths only)
+                        if (p + 4 >= s.size()) fail("bad \\u escape");
+                        const unsigned cp = (unsigned)std::stoul(s.substr(p + 1, 4), nullptr, 16); p += 4;
+                        if (cp < 0x80) v.str += (char)cp;
+                        else if (cp < 0x800) { v.str += (char)(0xC0 | (cp >> 6)); v.str += (char)(0x80 | (cp & 0x3F)); }
+                        else { v.str += (char)(0xE0 | (cp >> 12)); v.str += (char)(0x80 | ((cp >> 6) & 0x3F)); v.str += (char)(0x80 | (cp & 0x3F)); }
+                        break; }
+                    default: v.str += s[p];
+                    }
+                    p++;
+                } else v.str += s[p++];
+            }
+            if (p >= s.size()) fail("unterminated string");
+            p++;
+        } else if (!s.compare(p, 4, "true")) { p += 4; v.kind = Json::Bool; v.b = true; }
+        else if (!s.compare(p, 5, "false")) { p += 5; v.kind = Json::Bool; v.b = false; }
+        else if (!s.compare(p, 4, "null")) { p += 4; v.kind = Json::Null; }
+        else {
+            char* end = nullptr;
+            v.num = std::strtod(s.c_str() + p, &end);                     // correctly rounded, like Python's float()
+            if (end == s.c_str() + p) fail("value expected");
+            p = (size_t)(end - s.c_str()); v.kind = Json::Number;
+        }
+        return v;
+    }
+};
+
+inline std::string read_file(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+inline std::string dir_of(const std::string& path) { const size_t k = path.find_last_of('/'); return k == std::string::npos ? std::string(".") : path.substr(0, k); }
+inline std::string resolve(const std::string& base, const std::string& p) { return (p.empty() || p[0] == '/') ? p : base + "/" + p; }
+
+inline std::string base64_decode(const std::string& in)
+{
+    std::string out; unsigned acc = 0; int bits = 0;
+    for (unsigned char c : in) {
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A'; else if (c >= 'a' && c <= 'z') v = c - 'a' + 26; else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62; else if (c == '/' || c == '_') v = 63; else continue;     // '=' padding and whitespace are skipped
+        acc = (acc << 6) | (unsigned)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out += (char)((acc >> bits) & 0xFFu); }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SimpleMath / DirectXMath conventions (row vectors: v' = v M), in double like ingest.py
+// ------------------------------------------------------------------------------------------------
+struct M4 { double m[4][4]; };
+inline M4 identity() { M4 r{}; for (int i = 0; i < 4; i++) r.m[i][i] = 1.0; return r; }
+inline M4 mul(const M4& a, const M4& b)
+{
+    M4 r{};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0.0; for (int k = 0; k < 4; k++) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
+    return r;
+}
+inline M4 transpose(const M4& a) { M4 r{}; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i][j] = a.m[j][i]; return r; }
+inline M4 rot_x(double a) { const double c = std::cos(a), s = std::sin(a); M4 r = identity(); r.m[1][1] = c; r.m[1][2] = s; r.m[2][1] = -s; r.m[2][2] = c; return r; }
+inline M4 rot_y(double a) { const double c = std::cos(a), s = std::sin(a); M4 r = identity(); r.m[0][0] = c; r.m[0][2] = -s; r.m[2][0] = s; r.m[2][2] = c; return r; }
+inline M4 rot_z(double a) { const double c = std::cos(a), s = std::sin(a); M4 r = identity(); r.m[0][0] = c; r.m[0][1] = s; r.m[1][0] = -s; r.m[1][1] = c; return r; }
+inline M4 matrix_from_quaternion(double x, double y, double z, double w)
+{
+    M4 r = identity();
+    r.m[0][0] = 1 - 2 * (y * y + z * z); r.m[0][1] = 2 * (x * y + z * w); r.m[0][2] = 2 * (x * z - y * w);
+    r.m[1][0] = 2 * (x * y - z * w); r.m[1][1] = 1 - 2 * (x * x + z * z); r.m[1][2] = 2 * (y * z + x * w);
+    r.m[2][0] = 2 * (x * z + y * w); r.m[2][1] = 2 * (y * z - x * w); r.m[2][2] = 1 - 2 * (x * x + y * y);
+    return r;
+}
+inline double radians(double deg) { return deg * (M_PI / 180.0); }
+
+// JSONConverters.ixx:18-26: {Yaw,Pitch,Roll} in degrees -> CreateFromYawPitchRoll(yaw, -pitch, -roll) (roll about Z first, then pitch about X,
+// then yaw about Y); all three zero -> raw quaternion {X,Y,Z,W} (default identity)
+inline M4 rotation_from_json(const Json* j)
+{
+    if (!j || j->kind != Json::Object) return identity();
+    const double yaw = j->number("Yaw", 0), pitch = j->number("Pitch", 0), roll = j->number("Roll", 0);
+    if (yaw == 0 && pitch == 0 && roll == 0) {
+        double q[4] = { j->number("X", 0), j->number("Y", 0), j->number("Z", 0), j->number("W", 1) };
+        double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        if (n == 0.0) n = 1.0;
+        return matrix_from_quaternion(q[0] / n, q[1] / n, q[2] / n, q[3] / n);
+    }
+    return mul(mul(rot_z(radians(-roll)), rot_x(radians(-pitch))), rot_y(radians(yaw)));
+}
+inline void vec3_from_json(const Json* j, const double def[3], double out[3])
+{
+    out[0] = def[0]; out[1] = def[1]; out[2] = def[2];
+    if (j && j->kind == Json::Object) { out[0] = j->number("X", def[0]); out[1] = j->number("Y", def[1]); out[2] = j->number("Z", def[2]); }
+}
+// Math::AffineTransform::operator(): Scale * Rotation * Translation (row-vector)
+inline M4 affine_from_json(const Json* j)
+{
+    const double one[3] = { 1, 1, 1 }, zero[3] = { 0, 0, 0 };
+    double s[3], t[3];
+    vec3_from_json(j ? j->find("Scale") : nullptr, one, s); vec3_from_json(j ? j->find("Translation") : nullptr, zero, t);
+    M4 sc = identity(); sc.m[0][0] = s[0]; sc.m[1][1] = s[1]; sc.m[2][2] = s[2];
+    M4 m = mul(sc, rotation_from_json(j ? j->find("Rotation") : nullptr));
+    M4 tr = identity(); tr.m[3][0] = t[0]; tr.m[3][1] = t[1]; tr.m[3][2] = t[2];
+    return mul(m, tr);
+}
+// XMStoreFloat3x4: the column-vector affine [R|t] = top 3 rows of the transpose
+inline void store_float3x4(const M4& rowMajor, float out[12]) { for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) out[4 * i + j] = (float)rowMajor.m[j][i]; }
+
+// ------------------------------------------------------------------------------------------------
+// vertex packing (VertexPositionNormalTangentTexture, Source/Vertex.ixx:38-50)
+// ------------------------------------------------------------------------------------------------
+struct Vertex { float Position[3]; int16_t Normal[3], Tangent[3]; uint16_t TexCoord[2][2]; };
+static_assert(sizeof(Vertex) == 32, "layout");
+
+inline int16_t encode_snorm16(double v)
+{
+    v = std::fmin(std::fmax(v, -1.0), 1.0) * 32767.0;
+    return (int16_t)(v >= 0 ? std::floor(v + 0.5) : std::ceil(v - 0.5));
+}
+inline uint16_t f32_to_f16(float f)                                      // round to nearest even, like numpy's astype(float16)
+{
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, a = x & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);              // NaN
+    if (a >= 0x47800000u) return (uint16_t)(sign | 0x7C00u);             // >= 65536: infinity
+    if (a < 0x38800000u) {                                               // below 2^-14: a subnormal half (or zero) = round(|f| * 2^24)
+        float af; std::memcpy(&af, &a, 4);
+        return (uint16_t)(sign | (uint32_t)std::nearbyintf(af * 16777216.0f));     // exact scaling; nearbyint rounds to nearest even
+    }
+    const uint32_t mant = a & 0x7FFFFFu, rem = mant & 0x1FFFu;
+    uint32_t h = (((a >> 23) - 112u) << 10) | (mant >> 13);              // exponent rebias 127 -> 15
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;              // a carry runs into the exponent, up to infinity: still the right code
+    return (uint16_t)(sign | h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// model: glTF 2.0 (.gltf with data: / external buffers, .glb)
+// ------------------------------------------------------------------------------------------------
+struct MeshData {
+    std::vector<Vertex> Vertices;
+    std::vector<uint8_t> Indices; uint32_t IndexStride = 2, IndexCount = 0;      // u16 iff count <= 65535 (GLTFHelpers.ixx:183-188)
+    bool HasNormals = false, HasTangents = false, HasUV[2] = { false, false };
+    bool HasMaterial = false; PtMaterial Material{};
+    std::vector<std::string> SkippedTextures;                               // slots whose image this host cannot decode (no codec in the image)
+};
+struct MeshNode { std::vector<MeshData> Meshes; M4 GlobalTransform; };        // GlobalTransform reinterpreted as a row-vector matrix (LoadModel)
+
+inline PtMaterial default_material()
+{
+    PtMaterial m{};                                                            // Material() defaults, Source/Material.ixx:13-19
+    m.BaseColor[3] = 1; m.EmissiveStrength = 1; m.Roughness = 0.5f; m.IOR = 1.5f; m.AlphaCutoff = 0.5f;
+    return m;
+}
+
+class Asset {
+public:
+    explicit Asset(const std::string& path) : dir(dir_of(path))
+    {
+        const std::string raw = read_file(path);
+        if (raw.size() >= 12 && !raw.compare(0, 4, "glTF")) {
+            uint32_t length; std::memcpy(&length, raw.data() + 8, 4);
+            size_t off = 12;
+            while (off + 8 <= length && off + 8 <= raw.size()) {
+                uint32_t clen, ctype; std::memcpy(&clen, raw.data() + off, 4); std::memcpy(&ctype, raw.data() + off + 4, 4);
+                if (ctype == 0x4E4F534Au) j = JsonParser(jsonText = raw.substr(off + 8, clen)).parse();
+                else if (ctype == 0x004E4942u) { binChunk = raw.substr(off + 8, clen); haveBin = true; }
+                off += 8 + (size_t)clen;
+            }
+        } else j = JsonParser(jsonText = raw).parse();
+    }
+    Json j;
+
+    const std::string& buffer(size_t i)
+    {
+        auto it = buffers.find(i);
+        if (it != buffers.end()) return it->second;
+        const Json& b = j.at("buffers").at(i);
+        if (!b.has("uri")) { if (!haveBin) throw std::runtime_error("glTF: buffer without uri and no BIN chunk"); return buffers[i] = binChunk; }
+        const std::string& uri = b.at("uri").str;
+        if (!uri.compare(0, 5, "data:")) return buffers[i] = base64_decode(uri.substr(uri.find(',') + 1));
+        return buffers[i] = read_file(resolve(dir, uri));
+    }
+    // element (i, c) of an accessor as double (integers as they are; normalised integers divided by their maximum, in float like ingest.py)
+    struct Accessor { const uint8_t* data; size_t stride, count; int ncomp, ctype; bool normalized; };
+    Accessor accessor(size_t ai)
+    {
+        const Json& a = j.at("accessors").at(ai);
+        const Json& v = j.at("bufferViews").at((size_t)a.at("bufferView").num);
+        const std::string& b = buffer((size_t)v.at("buffer").num);
+        Accessor r;
+        r.ctype = (int)a.at("componentType").num;
+        const std::string& t = a.at("type").str;
+        r.ncomp = t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : t == "MAT4" ? 16 : 0;
+        if (!r.ncomp) throw std::runtime_error("glTF: accessor type " + t);
+        const size_t elem = (size_t)component_size(r.ctype) * r.ncomp, vstride = (size_t)v.number("byteStride", 0);
+        r.stride = (vstride == 0 || vstride == elem) ? elem : vstride;
+        r.count = (size_t)a.at("count").num;
+        const size_t off = (size_t)v.number("byteOffset", 0) + (size_t)a.number("byteOffset", 0);
+        if (off + (r.count ? (r.count - 1) * r.stride + elem : 0) > b.size()) throw std::runtime_error("glTF: accessor reaches beyond its buffer");
+        r.data = (const uint8_t*)b.data() + off;
+        const Json* n = a.find("normalized");
+        r.normalized = n && n->kind == Json::Bool && n->b;
+        return r;
+    }
+    static int component_size(int ctype)
+    {
+        switch (ctype) { case 5120: case 5121: return 1; case 5122: case 5123: return 2; case 5125: case 5126: return 4; }
+        throw std::runtime_error("glTF: component type " + std::to_string(ctype));
+    }
+    static double element(const Accessor& a, size_t i, int c)
+    {
+        const uint8_t* p = a.data + i * a.stride + (size_t)c * component_size(a.ctype);
+        double v; float maxv = 1.0f;
+        switch (a.ctype) {
+        case 5120: { int8_t x; std::memcpy(&x, p, 1); v = x; maxv = 127.0f; break; }
+        case 5121: { uint8_t x; std::memcpy(&x, p, 1); v = x; maxv = 255.0f; break; }
+        case 5122: { int16_t x; std::memcpy(&x, p, 2); v = x; maxv = 32767.0f; break; }
+        case 5123: { uint16_t x; std::memcpy(&x, p, 2); v = x; maxv = 65535.0f; break; }
+        case 5125: { uint32_t x; std::memcpy(&x, p, 4); v = x; maxv = 4294967295.0f; break; }
+        default: { float x; std::memcpy(&x, p, 4); return x; }
+        }
+        return a.normalized ? (double)((float)v / maxv) : v;
+    }
+
+private:
+    std::string dir, jsonText, binChunk; bool haveBin = false;
+    std::map<size_t, std::string> buffers;
+};
+
+// [DirectXMesh spec] ComputeTangentFrame (tangent output only): same operations in the same order as ingest.py's compute_tangents
+inline std::vector<std::array<double, 3>> compute_tangents(const std::vector<std::array<float, 3>>& pos, const std::vector<std::array<float, 3>>& nrm,
+                                                           const std::vector<std::array<float, 2>>& uv, const std::vector<uint32_t>& idx)
+{
+    std::vector<std::array<double, 3>> tan(pos.size(), { 0.0, 0.0, 0.0 });
+    for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+        const uint32_t a = idx[t], b = idx[t + 1], c = idx[t + 2];
+        double e1[3], e2[3];
+        for (int k = 0; k < 3; k++) { e1[k] = (double)pos[b][k] - (double)pos[a][k]; e2[k] = (double)pos[c][k] - (double)pos[a][k]; }
+        const double du1 = (double)uv[b][0] - (double)uv[a][0], dv1 = (double)uv[b][1] - (double)uv[a][1];
+        const double du2 = (double)uv[c][0] - (double)uv[a][0], dv2 = (double)uv[c][1] - (double)uv[a][1];
+        const double det = du1 * dv2 - du2 * dv1;
+        if (std::fabs(det) < 1e-20) continue;
+        for (int k = 0; k < 3; k++) { const double s = (e1[k] * dv2 - e2[k] * dv1) / det; tan[a][k] += s; tan[b][k] += s; tan[c][k] += s; }
+    }
+    for (size_t i = 0; i < pos.size(); i++) {
+        const double n[3] = { nrm[i][0], nrm[i][1], nrm[i][2] };
+        const double d = (n[0] * tan[i][0] + n[1] * tan[i][1]) + n[2] * tan[i][2];
+        double t[3] = { tan[i][0] - n[0] * d, tan[i][1] - n[1] * d, tan[i][2] - n[2] * d };
+        const double ln = std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+        double f[3] = { n[1] * 0.0 - n[2] * 1.0, n[2] * 0.0 - n[0] * 0.0, n[0] * 1.0 - n[1] * 0.0 };   // cross(n, (0, 1, 0))
+        const double fl = std::sqrt((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);
+        if (fl > 1e-8) { const double dd = std::fmax(fl, 1e-30); f[0] /= dd; f[1] /= dd; f[2] /= dd; } else { f[0] = 1.0; f[1] = 0.0; f[2] = 0.0; }
+        if (ln > 1e-12) { const double dd = std::fmax(ln, 1e-30); tan[i] = { t[0] / dd, t[1] / dd, t[2] / dd }; } else tan[i] = { f[0], f[1], f[2] };
+    }
+    return tan;
+}
+
+// glTF column-vector local matrix of a node
+inline M4 node_matrix(const Json& node)
+{
+    if (node.has("matrix")) { M4 c{}; const Json& m = node.at("matrix"); for (int i = 0; i < 16; i++) c.m[i / 4][i % 4] = m.at((size_t)i).num; return transpose(c); }   // column-major list
+    M4 t = identity(), r = identity(), s = identity();
+    if (node.has("translation")) for (int k = 0; k < 3; k++) t.m[k][3] = node.at("translation").at((size_t)k).num;
+    if (node.has("rotation")) { const Json& q = node.at("rotation"); r = transpose(matrix_from_quaternion(q.at(0).num, q.at(1).num, q.at(2).num, q.at(3).num)); }
+    if (node.has("scale")) for (int k = 0; k < 3; k++) s.m[k][k] = node.at("scale").at((size_t)k).num;
+    return mul(mul(t, r), s);
+}
+
+// GLTFHelpers::LoadModel: one MeshNode per glTF node that carries a mesh, with its global transform
+inline std::vector<std::shared_ptr<MeshNode>> load_model(const std::string& path, bool flipWindingOrder = true)
+{
+    Asset asset(path);
+    const Json& j = asset.j;
+    auto process_primitive = [&](const Json& prim, MeshData& mesh) -> bool {
+        if ((int)prim.number("mode", 4) != 4 || !prim.has("attributes") || !prim.at("attributes").has("POSITION") || !prim.has("indices")) return false;   // :150-152,169-171,191-193
+        const Json& attrs = prim.at("attributes");
+        const Asset::Accessor pa = asset.accessor((size_t)attrs.at("POSITION").num);
+        std::vector<std::array<float, 3>> pos(pa.count);
+        for (size_t i = 0; i < pa.count; i++) for (int k = 0; k < 3; k++) pos[i][k] = (float)Asset::element(pa, i, k);
+        const Asset::Accessor ia = asset.accessor((size_t)prim.at("indices").num);
+        std::vector<uint32_t> idx(ia.count);
+        for (size_t i = 0; i < ia.count; i++) idx[i] = (uint32_t)Asset::element(ia, i, 0);
+        if (flipWindingOrder) for (size_t i = 0; i < idx.size() / 2; i++) std::swap(idx[i], idx[idx.size() - 1 - i]);        // slot count-1-i <- index i (:179)
+        std::vector<std::array<float, 2>> uv[2];
+        for (int s = 0; s < 2; s++) {
+            const std::string name = "TEXCOORD_" + std::to_string(s);
+            if (!attrs.has(name)) continue;
+            const Asset::Accessor ua = asset.accessor((size_t)attrs.at(name).num);
+            uv[s].resize(ua.count);
+            for (size_t i = 0; i < ua.count; i++) for (int k = 0; k < 2; k++) uv[s][i][k] = (float)Asset::element(ua, i, k);
+            mesh.HasUV[s] = true;
+        }
+        std::vector<std::array<float, 3>> nrm; std::vector<std::array<double, 3>> tan;
+        if (attrs.has("NORMAL")) {
+            const Asset::Accessor na = asset.accessor((size_t)attrs.at("NORMAL").num);
+            nrm.resize(na.count);
+            for (size_t i = 0; i < na.count; i++) for (int k = 0; k < 3; k++) nrm[i][k] = (float)Asset::element(na, i, k);
+            mesh.HasNormals = true;
+            if (mesh.HasUV[0]) { tan = compute_tangents(pos, nrm, uv[0], idx); mesh.HasTangents = true; }     // "Tangent" is never found -> always recomputed (:251-275)
+        }
+        mesh.Vertices.assign(pos.size(), Vertex{});
+        for (size_t i = 0; i < pos.size(); i++) {
+            Vertex& v = mesh.Vertices[i];
+            for (int k = 0; k < 3; k++) {
+                v.Position[k] = pos[i][k];
+                if (mesh.HasNormals) v.Normal[k] = encode_snorm16((double)nrm[i][k]);
+                if (mesh.HasTangents) v.Tangent[k] = encode_snorm16(tan[i][k]);
+            }
+            for (int s = 0; s < 2; s++) if (mesh.HasUV[s]) for (int k = 0; k < 2; k++) v.TexCoord[s][k] = f32_to_f16(uv[s][i][k]);
+        }
+        mesh.IndexCount = (uint32_t)idx.size(); mesh.IndexStride = idx.size() <= 65535 ? 2u : 4u;
+        mesh.Indices.resize((size_t)mesh.IndexCount * mesh.IndexStride);
+        for (size_t i = 0; i < idx.size(); i++) {
+            if (mesh.IndexStride == 2) { const uint16_t x = (uint16_t)idx[i]; std::memcpy(mesh.Indices.data() + 2 * i, &x, 2); }
+            else std::memcpy(mesh.Indices.data() + 4 * i, &idx[i], 4);
+        }
+        if (prim.has("material")) {
+            const Json& m = j.at("materials").at((size_t)prim.at("material").num);
+            static const Json empty = [] { Json e; e.kind = Json::Object; return e; }();
+            const Json& pbr = m.has("pbrMetallicRoughness") ? m.at("pbrMetallicRoughness") : empty;
+            const Json& ext = m.has("extensions") ? m.at("extensions") : empty;
+            PtMaterial mat = default_material();
+            if (pbr.has("baseColorFactor")) for (int k = 0; k < 4; k++) mat.BaseColor[k] = (float)pbr.at("baseColorFactor").at((size_t)k).num;
+            else for (int k = 0; k < 4; k++) mat.BaseColor[k] = 1.0f;
+            mat.EmissiveStrength = ext.has("KHR_materials_emissive_strength") ? (float)ext.at("KHR_materials_emissive_strength").number("emissiveStrength", 1.0) : 1.0f;
+            for (int k = 0; k < 3; k++) mat.EmissiveColor[k] = m.has("emissiveFactor") ? (float)m.at("emissiveFactor").at((size_t)k).num : 0.0f;
+            mat.Metallic = (float)pbr.number("metallicFactor", 1.0);
+            mat.Roughness = (float)pbr.number("roughnessFactor", 1.0);
+            mat.IOR = ext.has("KHR_materials_ior") ? (float)ext.at("KHR_materials_ior").number("ior", 1.5) : 1.5f;
+            const std::string am = m.has("alphaMode") ? m.at("alphaMode").str : "OPAQUE";
+            mat.AlphaMode = am == "MASK" ? 1u : am == "BLEND" ? 2u : 0u;
+            mat.AlphaCutoff = (float)m.number("alphaCutoff", 0.5);
+            const Json* tr = ext.find("KHR_materials_transmission");
+            if (tr && tr->kind == Json::Object) mat.Transmission = (float)tr->number("transmissionFactor", 0.0);
+            mesh.Material = mat; mesh.HasMaterial = true;
+            if (mesh.HasUV[0] || mesh.HasUV[1]) {                          // :370-428 -- the slots a host with an image codec would fill
+                auto note = [&](const char* slot, const Json* info) {
+                    if (!info || info->kind != Json::Object) return;
+                    const int tc = (int)info->number("texCoord", 0);
+                    if (tc < 2 && mesh.HasUV[tc]) mesh.SkippedTextures.push_back(slot);
+                };
+                note("BaseColor", pbr.find("baseColorTexture")); note("EmissiveColor", m.find("emissiveTexture"));
+                note("MetallicRoughness", pbr.find("metallicRoughnessTexture"));
+                note("Transmission", tr ? tr->find("transmissionTexture") : nullptr);
+                if (mesh.HasTangents) note("Normal", m.find("normalTexture"));
+            }
+        }
+        return true;
+    };
+
+    std::vector<std::shared_ptr<MeshNode>> out;
+    const Json& scene = j.at("scenes").at((size_t)j.number("scene", 0));
+    std::function<void(size_t, const M4&)> visit = [&](size_t ni, const M4& parent) {
+        const Json& node = j.at("nodes").at(ni);
+        const M4 m = mul(parent, node_matrix(node));
+        if (node.has("mesh")) {
+            const Json& mj = j.at("meshes").at((size_t)node.at("mesh").num);
+            if (mj.has("primitives") && mj.at("primitives").size()) {
+                auto mn = std::make_shared<MeshNode>();
+                for (const Json& p : mj.at("primitives").arr) { MeshData md; if (process_primitive(p, md)) mn->Meshes.push_back(std::move(md)); }
+                mn->GlobalTransform = transpose(m);                       // the column-vector global matrix reinterpreted as a row-vector Matrix
+                out.push_back(mn);
+            }
+        }
+        if (node.has("children")) for (const Json& c : node.at("children").arr) visit((size_t)c.num, m);
+    };
+    if (scene.has("nodes")) for (const Json& n : scene.at("nodes").arr) visit((size_t)n.num, identity());
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scene descriptor + Scene::Load / Refresh
+// ------------------------------------------------------------------------------------------------
+struct RenderObject { uint32_t Node; float Transform[12]; bool IsVisible; std::string Name; };   // Transform: column-vector [R|t], as InstanceData.ObjectToWorld wants it
+struct Scene {
+    double CameraPosition[3] = { 0, 0, 0 }; M4 CameraRotation = identity();
+    float EnvironmentLightColor[4] = { 0, 0, 0, -1 }; float EnvironmentLightTransform[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    std::string EnvironmentLightTexture;                                    // path, not decoded here
+    std::vector<std::shared_ptr<MeshNode>> Nodes;                           // one bottom level each
+    std::vector<RenderObject> Objects;                                      // one instance each
+};
+
+inline Scene load_scene(const std::string& path)
+{
+    const Json j = JsonParser(read_file(path)).parse();
+    const std::string base = dir_of(path);
+    Scene sc;
+    const double zero[3] = { 0, 0, 0 };
+    const Json* cam = j.find("Camera");
+    vec3_from_json(cam ? cam->find("Position") : nullptr, zero, sc.CameraPosition);
+    sc.CameraRotation = rotation_from_json(cam ? cam->find("Rotation") : nullptr);
+    const Json* env = j.find("EnvironmentLight");
+    if (env && env->kind == Json::Object) {
+        if (const Json* col = env->find("Color"); col && col->kind == Json::Object) {
+            sc.EnvironmentLightColor[0] = (float)col->number("R", 0); sc.EnvironmentLightColor[1] = (float)col->number("G", 0);
+            sc.EnvironmentLightColor[2] = (float)col->number("B", 0); sc.EnvironmentLightColor[3] = (float)col->number("A", -1);
+        } else sc.EnvironmentLightColor[3] = -1;
+        store_float3x4(rotation_from_json(env->find("Rotation")), sc.EnvironmentLightTransform);     // App.cpp:1019
+        if (env->has("Texture")) sc.EnvironmentLightTexture = resolve(base, env->at("Texture").str);
+    }
+    std::map<std::string, std::string> models;
+    if (const Json* m = j.find("Models"); m && m->kind == Json::Object) for (auto& kv : m->obj) models[kv.first] = resolve(base, kv.second.str);
+    std::map<std::string, std::vector<std::shared_ptr<MeshNode>>> loaded;
+    M4 zflip = identity(); zflip.m[2][2] = -1.0;
+    if (const Json* ros = j.find("RenderObjects"); ros && ros->kind == Json::Array)
+        for (const Json& ro : ros->arr) {
+            const std::string model = ro.has("Model") ? ro.at("Model").str : "", name = ro.has("Name") ? ro.at("Name").str : "";
+            if (!model.empty() && !models.count(model))                    // MyScene.ixx:57-70
+                throw std::runtime_error(path + ": " + (name.empty() ? std::string("Unnamed RenderObject") : "RenderObject " + name) + ": Models " + model + " not found");
+            if (model.empty()) continue;
+            if (!loaded.count(model)) loaded[model] = load_model(models[model], true);      // Scene.ixx:90
+            const M4 transform = affine_from_json(ro.find("Transform"));
+            const Json* vis = ro.find("IsVisible");
+            for (auto& mn : loaded[model]) {
+                uint32_t ni = 0;
+                for (; ni < sc.Nodes.size(); ni++) if (sc.Nodes[ni] == mn) break;
+                if (ni == sc.Nodes.size()) sc.Nodes.push_back(mn);
+                RenderObject o; o.Node = ni; o.Name = name; o.IsVisible = !(vis && vis->kind == Json::Bool && !vis->b);
+                store_float3x4(mul(mul(mn->GlobalTransform, zflip), transform), o.Transform);     // Scene.ixx:199-214
+                sc.Objects.push_back(o);
+            }
+        }
+    return sc;
+}
+
+} // namespace ptamd::ingest
