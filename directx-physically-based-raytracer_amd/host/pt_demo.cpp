@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -115,7 +117,8 @@ template <typename T> static T* upload(const std::vector<T>& v)
 // What the host hands the library, whichever way it came about (built in code below, or loaded by pt_ingest.hpp): mesh nodes (one bottom level
 // each, one geometry per mesh), instances of them, a camera and the environment.
 struct HostGeometry { std::vector<uint8_t> vertices; uint32_t vertexCount = 0; std::vector<uint8_t> indices; uint32_t indexCount = 0, indexStride = 2;
-                      bool hasNormals = true, hasTangents = false, hasUV[2] = { false, false }; PtMaterial material{}; };
+                      bool hasNormals = true, hasTangents = false, hasUV[2] = { false, false }; PtMaterial material{};
+                      std::shared_ptr<ingest::Texture> textures[7]; uint32_t texCoord[7] = { 0, 0, 0, 0, 0, 0, 0 }; };   // slots in the order of Material.ixx:22-33
 struct HostNode { std::vector<HostGeometry> meshes; };
 struct HostObject { uint32_t node = 0; float transform[12]; bool visible = true; };
 struct HostScene {
@@ -175,7 +178,8 @@ static HostScene ingested_scene(const std::string& path)
             g.indices = md.Indices; g.indexCount = md.IndexCount; g.indexStride = md.IndexStride;
             g.hasNormals = md.HasNormals; g.hasTangents = md.HasTangents; g.hasUV[0] = md.HasUV[0]; g.hasUV[1] = md.HasUV[1];
             g.material = md.HasMaterial ? md.Material : ingest::default_material();            // App.cpp:1044: Material() when a mesh names none
-            for (const std::string& slot : md.SkippedTextures) fprintf(stderr, "pt_demo: %s texture of a material not loaded (no image codec in this host)\n", slot.c_str());
+            for (int k = 0; k < 7; k++) { g.textures[k] = md.Textures[k]; g.texCoord[k] = md.TextureCoordinateIndex[k]; }
+            for (const std::string& slot : md.SkippedTextures) fprintf(stderr, "pt_demo: %s texture of a material not loaded (this host decodes 8-bit PNG only)\n", slot.c_str());
             n.meshes.push_back(std::move(g));
         }
         sc.nodes.push_back(std::move(n));
@@ -228,9 +232,15 @@ static int dump_scene(const HostScene& sc, const std::string& path)
         printf("%s[", n ? ", " : "");
         for (size_t m = 0; m < sc.nodes[n].meshes.size(); m++) {
             const HostGeometry& g = sc.nodes[n].meshes[m];
-            printf("%s{\"vertices\": %u, \"indices\": %u, \"index_stride\": %u, \"has_normals\": %d, \"has_tangents\": %d, \"has_uv\": [%d, %d]}", m ? ", " : "",
+            printf("%s{\"vertices\": %u, \"indices\": %u, \"index_stride\": %u, \"has_normals\": %d, \"has_tangents\": %d, \"has_uv\": [%d, %d], \"textures\": [", m ? ", " : "",
                    g.vertexCount, g.indexCount, g.indexStride, g.hasNormals, g.hasTangents, g.hasUV[0], g.hasUV[1]);
             fwrite(g.vertices.data(), 1, g.vertices.size(), fp); fwrite(g.indices.data(), 1, g.indices.size(), fp); fwrite(&g.material, sizeof(PtMaterial), 1, fp);
+            bool firstTex = true;
+            for (int k = 0; k < 7; k++) if (g.textures[k]) {              // slot, size, sRGB, coordinate set; the texels follow the material in the file
+                printf("%s[%d, %u, %u, %d, %u]", firstTex ? "" : ", ", k, g.textures[k]->Texels.Width, g.textures[k]->Texels.Height, g.textures[k]->SRGB ? 1 : 0, g.texCoord[k]);
+                fwrite(g.textures[k]->Texels.RGBA.data(), 1, g.textures[k]->Texels.RGBA.size(), fp); firstTex = false;
+            }
+            printf("]}");
         }
         printf("]");
     }
@@ -345,8 +355,24 @@ int main(int argc, char** argv)
 
         // ---- buffers, descriptor heap, bottom levels (Scene::CreateAccelerationStructures: one per mesh node, one geometry per mesh)
         uint32_t heapSize = 0;
-        for (const HostNode& nd : scene.nodes) heapSize += 2 * (uint32_t)nd.meshes.size();
+        std::map<const ingest::Texture*, uint32_t> textureDescriptor;        // one descriptor per texture, however many meshes share it
+        for (const HostNode& nd : scene.nodes) {
+            heapSize += 2 * (uint32_t)nd.meshes.size();
+            for (const HostGeometry& hg : nd.meshes) for (auto& t : hg.textures) if (t && !textureDescriptor.count(t.get())) textureDescriptor[t.get()] = 0;
+        }
+        const uint32_t firstTextureDescriptor = heapSize;
+        heapSize += (uint32_t)textureDescriptor.size();
         ThrowIfFailed(commandList.Context, pt_heap_resize(commandList.Context, heapSize));
+        {
+            uint32_t next = firstTextureDescriptor;
+            for (auto& kv : textureDescriptor) {                             // texel arrays as pt_heap_set_texture takes them (App.cpp:1052-1063 fills the descriptor indices)
+                kv.second = next++;
+                const ingest::Image& im = kv.first->Texels;
+                uint8_t* dt = upload(im.RGBA);
+                ThrowIfFailed(commandList.Context, pt_heap_set_texture(commandList.Context, kv.second, dt, im.Width, im.Height,
+                                                                       kv.first->SRGB ? PT_FORMAT_R8G8B8A8_UNORM_SRGB : PT_FORMAT_R8G8B8A8_UNORM, 0));
+            }
+        }
         struct GeometryOnDevice { uint32_t heapVertices, heapIndices; };
         std::vector<std::vector<GeometryOnDevice>> onDevice(scene.nodes.size());
         std::vector<uint64_t> blas(scene.nodes.size());
@@ -379,7 +405,10 @@ int main(int argc, char** argv)
                 od.VertexDesc.AttributeOffsets.TextureCoordinates[0] = hg.hasUV[0] ? 24u : ~0u; od.VertexDesc.AttributeOffsets.TextureCoordinates[1] = hg.hasUV[1] ? 28u : ~0u;
                 od.MeshDescriptors.Vertices = onDevice[ho.node][g].heapVertices; od.MeshDescriptors.Indices = onDevice[ho.node][g].heapIndices; od.MeshDescriptors.MotionVectors = ~0u;
                 od.Material = hg.material;
-                for (auto& t : od.TextureMapInfoArray) t.Descriptor = ~0u;
+                for (int k = 0; k < 7; k++) {
+                    od.TextureMapInfoArray[k].Descriptor = hg.textures[k] ? textureDescriptor[hg.textures[k].get()] : ~0u;
+                    od.TextureMapInfoArray[k].TextureCoordinateIndex = hg.texCoord[k];
+                }
                 objectData.push_back(od);
             }
             PtInstanceData& id = instanceData[i]; memset(&id, 0, sizeof id);

@@ -11,9 +11,9 @@
 //                      AffineTransform = Scale * Rotation * Translation (Math.ixx:17-19)
 // Same conventions, same arithmetic order as the test harness's ingest.py, so that both hosts hand the library the same bytes
 // (tests/test_host_cpp.py compares vertex / index buffers, transforms and materials of the committed fixture, and the rendered frame).
-// Not here: image codecs. The reference decodes texture files with DirectXTex / stb behind TextureHelpers.ixx; this image has neither, so
-// texture references of a material are listed in MeshData::SkippedTextures and the material keeps its factors (the library takes textures
-// as texel arrays through pt_heap_set_texture: a host with a decoder fills the slots there).
+// Textures: 8-bit PNG images (embedded or referenced) are decoded here (a small inflate + the PNG filters, checked against PIL); the reference
+// decodes files with DirectXTex / stb behind TextureHelpers.ixx, this image has neither, so JPEG / DDS / 16-bit references are listed in
+// MeshData::SkippedTextures and the material keeps its factors (a host with a codec fills those slots through pt_heap_set_texture).
 // [DirectXMesh spec] ComputeTangentFrame is an un-vendored dependency: restated as Lengyel's per-vertex accumulation with Gram-Schmidt
 // against the normal (as in ingest.py). Header-only, C++20, no dependency beyond the standard library and include/ptamd.h.
 #pragma once
@@ -140,6 +140,172 @@ inline std::string base64_decode(const std::string& in)
 }
 
 // ------------------------------------------------------------------------------------------------
+// PNG (the lossless half of what glTF embeds; JPEG / DDS need a codec this image does not have: such textures are listed and skipped)
+// ------------------------------------------------------------------------------------------------
+// RFC 1951 inflate (stored, fixed and dynamic Huffman blocks) behind the RFC 1950 zlib header; canonical-code decoding by counts per length.
+class Inflate {
+public:
+    static std::vector<uint8_t> zlib(const uint8_t* src, size_t n)
+    {
+        if (n < 6 || (src[0] & 0x0F) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) throw std::runtime_error("PNG: bad zlib header");
+        Inflate z(src + 2, n - 2);
+        z.run();
+        return std::move(z.out);
+    }
+
+private:
+    Inflate(const uint8_t* s, size_t n) : in(s), size(n) {}
+    const uint8_t* in; size_t size, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0;
+    std::vector<uint8_t> out;
+    struct Huffman { uint16_t count[16]; uint16_t symbol[288]; };
+
+    uint32_t bits(int need)
+    {
+        uint32_t v = bitbuf;
+        while (bitcnt < need) { if (pos >= size) throw std::runtime_error("PNG: deflate stream ends early"); v |= (uint32_t)in[pos++] << bitcnt; bitcnt += 8; }
+        bitbuf = need < 32 ? v >> need : 0; bitcnt -= need;
+        return need < 32 ? v & ((1u << need) - 1u) : v;
+    }
+    static void build(Huffman& h, const uint8_t* lengths, int n)
+    {
+        for (int i = 0; i < 16; i++) h.count[i] = 0;
+        for (int i = 0; i < n; i++) h.count[lengths[i]]++;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = (uint16_t)(offs[i] + h.count[i]);
+        for (int i = 0; i < n; i++) if (lengths[i]) h.symbol[offs[lengths[i]]++] = (uint16_t)i;
+        h.count[0] = 0;
+    }
+    int decode(const Huffman& h)
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= (int)bits(1);
+            const int count = h.count[len];
+            if (code - count < first) return h.symbol[index + (code - first)];
+            index += count; first += count; first <<= 1; code <<= 1;
+        }
+        throw std::runtime_error("PNG: bad Huffman code");
+    }
+    void codes(const Huffman& lencode, const Huffman& distcode)
+    {
+        static const uint16_t lbase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+        static const uint16_t lext[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+        static const uint16_t dbase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+        static const uint16_t dext[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+        for (;;) {
+            int sym = decode(lencode);
+            if (sym < 256) out.push_back((uint8_t)sym);
+            else if (sym == 256) return;
+            else {
+                sym -= 257;
+                if (sym >= 29) throw std::runtime_error("PNG: bad length symbol");
+                const int len = lbase[sym] + (int)bits(lext[sym]);
+                const int ds = decode(distcode);
+                if (ds >= 30) throw std::runtime_error("PNG: bad distance symbol");
+                const size_t dist = dbase[ds] + bits(dext[ds]);
+                if (dist > out.size()) throw std::runtime_error("PNG: distance beyond the window");
+                for (int k = 0; k < len; k++) out.push_back(out[out.size() - dist]);
+            }
+        }
+    }
+    void run()
+    {
+        for (bool last = false; !last;) {
+            last = bits(1) != 0;
+            const uint32_t type = bits(2);
+            if (type == 0) {
+                bitbuf = 0; bitcnt = 0;
+                if (pos + 4 > size) throw std::runtime_error("PNG: stored block ends early");
+                const uint32_t len = in[pos] | (in[pos + 1] << 8), nlen = in[pos + 2] | (in[pos + 3] << 8);
+                pos += 4;
+                if ((len ^ 0xFFFFu) != nlen || pos + len > size) throw std::runtime_error("PNG: bad stored block");
+                out.insert(out.end(), in + pos, in + pos + len); pos += len;
+            } else if (type == 1) {
+                uint8_t l[288];
+                for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                Huffman lc, dc; build(lc, l, 288);
+                uint8_t d[30]; for (int i = 0; i < 30; i++) d[i] = 5;
+                build(dc, d, 30);
+                codes(lc, dc);
+            } else if (type == 2) {
+                static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+                const int nlen = (int)bits(5) + 257, ndist = (int)bits(5) + 1, ncode = (int)bits(4) + 4;
+                if (nlen > 286 || ndist > 30) throw std::runtime_error("PNG: bad dynamic block header");
+                uint8_t l[320] = { 0 };
+                for (int i = 0; i < ncode; i++) l[order[i]] = (uint8_t)bits(3);
+                Huffman cl; build(cl, l, 19);
+                uint8_t lengths[320]; int idx = 0;
+                while (idx < nlen + ndist) {
+                    int sym = decode(cl);
+                    if (sym < 16) lengths[idx++] = (uint8_t)sym;
+                    else {
+                        uint8_t prev = 0; int rep;
+                        if (sym == 16) { if (!idx) throw std::runtime_error("PNG: repeat without a previous length"); prev = lengths[idx - 1]; rep = 3 + (int)bits(2); }
+                        else if (sym == 17) rep = 3 + (int)bits(3); else rep = 11 + (int)bits(7);
+                        if (idx + rep > nlen + ndist) throw std::runtime_error("PNG: too many code lengths");
+                        while (rep--) lengths[idx++] = prev;
+                    }
+                }
+                Huffman lc, dc; build(lc, lengths, nlen); build(dc, lengths + nlen, ndist);
+                codes(lc, dc);
+            } else throw std::runtime_error("PNG: bad block type");
+        }
+    }
+};
+
+struct Image { uint32_t Width = 0, Height = 0; std::vector<uint8_t> RGBA; };       // 8 bits per channel, rows top to bottom
+
+inline bool is_png(const std::string& d) { return d.size() >= 8 && !std::memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8); }
+
+// 8-bit grey / grey+alpha / RGB / RGBA / palette PNG without interlacing -> RGBA8, as PIL's Image.open(...).convert("RGBA") delivers it
+inline Image decode_png(const std::string& d)
+{
+    if (!is_png(d)) throw std::runtime_error("not a PNG");
+    auto be32 = [&](size_t o) { return ((uint32_t)(uint8_t)d[o] << 24) | ((uint32_t)(uint8_t)d[o + 1] << 16) | ((uint32_t)(uint8_t)d[o + 2] << 8) | (uint32_t)(uint8_t)d[o + 3]; };
+    Image im; int depth = 0, ctype = 0, interlace = 0;
+    std::string idat; std::vector<uint8_t> palette, trns;
+    for (size_t o = 8; o + 12 <= d.size();) {
+        const uint32_t len = be32(o); const std::string type = d.substr(o + 4, 4);
+        if (o + 12 + (size_t)len > d.size()) throw std::runtime_error("PNG: chunk reaches beyond the file");
+        if (type == "IHDR") { im.Width = be32(o + 8); im.Height = be32(o + 12); depth = (uint8_t)d[o + 16]; ctype = (uint8_t)d[o + 17]; interlace = (uint8_t)d[o + 20]; }
+        else if (type == "PLTE") palette.assign(d.begin() + (long)o + 8, d.begin() + (long)o + 8 + len);
+        else if (type == "tRNS") trns.assign(d.begin() + (long)o + 8, d.begin() + (long)o + 8 + len);
+        else if (type == "IDAT") idat.append(d, o + 8, len);
+        else if (type == "IEND") break;
+        o += 12 + (size_t)len;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!channels || depth != 8 || interlace || !im.Width || !im.Height) throw std::runtime_error("PNG: only 8-bit non-interlaced images are decoded here");
+    const std::vector<uint8_t> raw = Inflate::zlib((const uint8_t*)idat.data(), idat.size());
+    const size_t bpp = (size_t)channels, stride = (size_t)im.Width * bpp;
+    if (raw.size() < (stride + 1) * im.Height) throw std::runtime_error("PNG: image data too short");
+    std::vector<uint8_t> px(stride * im.Height);
+    for (uint32_t y = 0; y < im.Height; y++) {                                      // undo the scanline filters (PNG spec 9.2)
+        const uint8_t* src = raw.data() + (stride + 1) * y; const int f = src[0]; src++;
+        uint8_t* cur = px.data() + stride * y; const uint8_t* up = y ? cur - stride : nullptr;
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int v = src[x];
+            if (f == 1) v += a; else if (f == 2) v += b; else if (f == 3) v += (a + b) >> 1;
+            else if (f == 4) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (f != 0) throw std::runtime_error("PNG: bad filter type");
+            cur[x] = (uint8_t)v;
+        }
+    }
+    im.RGBA.resize((size_t)im.Width * im.Height * 4);
+    for (size_t i = 0; i < (size_t)im.Width * im.Height; i++) {
+        uint8_t* o = im.RGBA.data() + 4 * i; const uint8_t* s = px.data() + bpp * i;
+        if (ctype == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+        else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 255; }
+        else if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+        else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+        else { const size_t k = s[0]; if (3 * k + 3 > palette.size()) throw std::runtime_error("PNG: palette index out of range");
+               o[0] = palette[3 * k]; o[1] = palette[3 * k + 1]; o[2] = palette[3 * k + 2]; o[3] = k < trns.size() ? trns[k] : 255; }
+    }
+    return im;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SimpleMath / DirectXMath conventions (row vectors: v' = v M), in double like ingest.py
 // ------------------------------------------------------------------------------------------------
 struct M4 { double m[4][4]; };
@@ -232,8 +398,13 @@ struct MeshData {
     std::vector<uint8_t> Indices; uint32_t IndexStride = 2, IndexCount = 0;      // u16 iff count <= 65535 (GLTFHelpers.ixx:183-188)
     bool HasNormals = false, HasTangents = false, HasUV[2] = { false, false };
     bool HasMaterial = false; PtMaterial Material{};
-    std::vector<std::string> SkippedTextures;                               // slots whose image this host cannot decode (no codec in the image)
+    // texture slots in the order of Material.ixx:22-33 (BaseColor, EmissiveColor, Metallic, Roughness, MetallicRoughness, Transmission, Normal);
+    // textures are shared between the meshes of a model by (image, sRGB) like the reference's and the harness's loaders share them
+    std::shared_ptr<struct Texture> Textures[7]; uint32_t TextureCoordinateIndex[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    std::vector<std::string> SkippedTextures;                               // slots whose image this host cannot decode (anything but 8-bit PNG)
 };
+struct Texture { Image Texels; bool SRGB = false; };                        // base-colour / emissive textures are created as *_UNORM_SRGB (GLTFHelpers.ixx:375-391)
+enum TextureSlot { BaseColor = 0, EmissiveColor, Metallic, Roughness, MetallicRoughness, Transmission, Normal };
 struct MeshNode { std::vector<MeshData> Meshes; M4 GlobalTransform; };        // GlobalTransform reinterpreted as a row-vector matrix (LoadModel)
 
 inline PtMaterial default_material()
@@ -313,6 +484,21 @@ public:
         return a.normalized ? (double)((float)v / maxv) : v;
     }
 
+    // the encoded bytes of image ii (data: / file uri, or a buffer view)
+    std::string image_bytes(size_t ii)
+    {
+        const Json& im = j.at("images").at(ii);
+        if (im.has("uri")) {
+            const std::string& uri = im.at("uri").str;
+            return !uri.compare(0, 5, "data:") ? base64_decode(uri.substr(uri.find(',') + 1)) : read_file(resolve(dir, uri));
+        }
+        const Json& v = j.at("bufferViews").at((size_t)im.at("bufferView").num);
+        const std::string& b = buffer((size_t)v.at("buffer").num);
+        const size_t off = (size_t)v.number("byteOffset", 0), len = (size_t)v.at("byteLength").num;
+        if (off + len > b.size()) throw std::runtime_error("glTF: image reaches beyond its buffer");
+        return b.substr(off, len);
+    }
+
 private:
     std::string dir, jsonText, binChunk; bool haveBin = false;
     std::map<size_t, std::string> buffers;
@@ -362,6 +548,17 @@ inline std::vector<std::shared_ptr<MeshNode>> load_model(const std::string& path
 {
     Asset asset(path);
     const Json& j = asset.j;
+    std::map<std::pair<size_t, bool>, std::shared_ptr<Texture>> textureCache;          // (image, forced sRGB) -> texture; nullptr: not decodable here
+    auto texture_for = [&](const Json& info, bool forceSrgb) -> std::shared_ptr<Texture> {
+        const size_t src = (size_t)j.at("textures").at((size_t)info.at("index").num).at("source").num;
+        const auto key = std::make_pair(src, forceSrgb);
+        auto it = textureCache.find(key);
+        if (it != textureCache.end()) return it->second;
+        std::shared_ptr<Texture> t;
+        const std::string bytes = asset.image_bytes(src);
+        if (is_png(bytes)) { try { t = std::make_shared<Texture>(); t->Texels = decode_png(bytes); t->SRGB = forceSrgb; } catch (const std::exception&) { t.reset(); } }
+        return textureCache[key] = t;
+    };
     auto process_primitive = [&](const Json& prim, MeshData& mesh) -> bool {
         if ((int)prim.number("mode", 4) != 4 || !prim.has("attributes") || !prim.at("attributes").has("POSITION") || !prim.has("indices")) return false;   // :150-152,169-171,191-193
         const Json& attrs = prim.at("attributes");
@@ -424,16 +621,18 @@ inline std::vector<std::shared_ptr<MeshNode>> load_model(const std::string& path
             const Json* tr = ext.find("KHR_materials_transmission");
             if (tr && tr->kind == Json::Object) mat.Transmission = (float)tr->number("transmissionFactor", 0.0);
             mesh.Material = mat; mesh.HasMaterial = true;
-            if (mesh.HasUV[0] || mesh.HasUV[1]) {                          // :370-428 -- the slots a host with an image codec would fill
-                auto note = [&](const char* slot, const Json* info) {
+            if (mesh.HasUV[0] || mesh.HasUV[1]) {                          // :370-428
+                auto slot = [&](TextureSlot k, const char* name, const Json* info, bool srgb) {
                     if (!info || info->kind != Json::Object) return;
                     const int tc = (int)info->number("texCoord", 0);
-                    if (tc < 2 && mesh.HasUV[tc]) mesh.SkippedTextures.push_back(slot);
+                    if (tc >= 2 || !mesh.HasUV[tc]) return;
+                    if (auto t = texture_for(*info, srgb)) { mesh.Textures[k] = t; mesh.TextureCoordinateIndex[k] = (uint32_t)tc; }
+                    else mesh.SkippedTextures.push_back(name);
                 };
-                note("BaseColor", pbr.find("baseColorTexture")); note("EmissiveColor", m.find("emissiveTexture"));
-                note("MetallicRoughness", pbr.find("metallicRoughnessTexture"));
-                note("Transmission", tr ? tr->find("transmissionTexture") : nullptr);
-                if (mesh.HasTangents) note("Normal", m.find("normalTexture"));
+                slot(BaseColor, "BaseColor", pbr.find("baseColorTexture"), true); slot(EmissiveColor, "EmissiveColor", m.find("emissiveTexture"), true);
+                slot(MetallicRoughness, "MetallicRoughness", pbr.find("metallicRoughnessTexture"), false);
+                slot(Transmission, "Transmission", tr ? tr->find("transmissionTexture") : nullptr, false);
+                if (mesh.HasTangents) slot(Normal, "Normal", m.find("normalTexture"), false);   // a normal map needs the tangent frame
             }
         }
         return true;

@@ -10,6 +10,7 @@ import pytest
 import __graft_entry__ as ge
 
 DEMO = os.path.join(ge.PKG_DIR, "pt_demo")
+S_SLOTS = ["BaseColor", "EmissiveColor", "Metallic", "Roughness", "MetallicRoughness", "Transmission", "Normal"]   # Material.ixx:22-33
 
 
 def test_cpp_mirror_header_compiles_standalone(tmp_path):
@@ -67,6 +68,13 @@ def _compare_dump_with_harness(path, dump, info, ingest, L):
             assert raw[off:off + len(ib)] == ib, (n, m, "indices"); off += len(ib)
             mat = np.array(mesh.material if mesh.material is not None else L.default_material())
             assert raw[off:off + 56] == mat.tobytes()[:56], (n, m, "material"); off += 64          # (the last 8 bytes are padding)
+            want = {S_SLOTS.index(slot): (tex, uvi) for slot, (tex, uvi) in (mesh.textures or {}).items()}
+            assert sorted(t[0] for t in meta["textures"]) == sorted(want), (n, m, "texture slots")
+            for slot, w, h, srgb, tc in meta["textures"]:
+                tex, uvi = want[slot]
+                assert (h, w) == tex.data.shape[:2] and bool(srgb) == bool(tex.srgb) and tc == uvi, (n, m, slot)
+                nb = w * h * 4
+                assert raw[off:off + nb] == np.ascontiguousarray(tex.data).tobytes(), (n, m, slot, "texels"); off += nb
     assert [(o["node"], bool(o["visible"])) for o in info["objects"]] == [(ro.node, bool(ro.visible)) for ro in sc.objects]
     for i, ro in enumerate(sc.objects):
         assert raw[off:off + 48] == np.ascontiguousarray(ro.transform, np.float32).tobytes(), ("transform", i); off += 48
@@ -92,13 +100,22 @@ def test_cpp_ingest_hands_the_library_the_same_bytes(tmp_path, pkg):
         dump = str(tmp_path / (name + ".bin"))
         info = json.loads(subprocess.check_output([DEMO, "--scene", os.path.join(fixtures, name), "--dump-scene", dump], text=True))
         _compare_dump_with_harness(os.path.join(fixtures, name), dump, info, I, L)
-    # a scene with UVs on two sets, tangents, every material factor and texture references (which the C++ host lists and skips: no image codec)
+    # a scene with UVs on two sets, tangents, every material factor and embedded PNG textures in five slots (the C++ host decodes 8-bit PNG itself:
+    # its texels must be PIL's)
     path = I.export_scene(S.cornell_box_textured(env=None), str(tmp_path), "cornell")
     dump = str(tmp_path / "cornell_dump.out")
     p = subprocess.run([DEMO, "--scene", path, "--dump-scene", dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
     sc = _compare_dump_with_harness(path, dump, json.loads(p.stdout), I, L)
     n_tex = sum(len(m.textures or {}) for node in sc.nodes for m in node.meshes)
-    assert n_tex > 0 and p.stderr.count("not loaded") == n_tex
+    assert n_tex >= 5 and "not loaded" not in p.stderr
+    # an image this host cannot decode (JPEG) is listed and skipped; the material keeps its factors
+    from PIL import Image
+    g = json.load(open(os.path.join(str(tmp_path), "cornell_node0.gltf")))
+    Image.fromarray(np.full((8, 8, 3), 128, np.uint8)).save(str(tmp_path / "t.jpg"))
+    g["images"] = [{"uri": "t.jpg"}] + g["images"][1:]
+    json.dump(g, open(os.path.join(str(tmp_path), "cornell_node0.gltf"), "w"))
+    q = subprocess.run([DEMO, "--scene", path, "--dump-scene", str(tmp_path / "y.out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, check=True)
+    assert "not loaded" in q.stderr
     # a missing model reference fails like the reference does (MyScene.ixx:57-70)
     bad = tmp_path / "bad.json"
     bad.write_text(json.dumps({"Models": {}, "RenderObjects": [{"Name": "a", "Model": "nope"}]}))
@@ -108,13 +125,14 @@ def test_cpp_ingest_hands_the_library_the_same_bytes(tmp_path, pkg):
 
 @pytest.mark.gpu
 def test_cpp_host_renders_an_ingested_scene_like_the_harness(tmp_path, gpu, ptamd, pkg):
-    """pt_demo --scene: descriptor -> pt_ingest.hpp -> bottom levels with several geometries, hidden instances, materials -> rendered frame;
-    bit-identical to the same descriptor loaded by ingest.py and rendered through the Python binding."""
+    """pt_demo --scene: descriptor -> pt_ingest.hpp (glTF geometry, recomputed tangents, materials, embedded PNG textures in five slots, an
+    alpha-masked mesh) -> descriptor heap, object data, bottom levels -> rendered frame; bit-identical to the same descriptor loaded by
+    ingest.py (PIL decodes the images there) and rendered through the Python binding."""
     ge.load_package()
     import dxpbrt_amd.ingest as I
     S = pkg.scenes
     W, H, spp, bounces = 160, 90, 2, 4
-    src = S.cornell_box(aspect=W / H, variant="ggx", glass_sphere=True)
+    src = S.cornell_box_textured(aspect=W / H, env=None)
     path = I.export_scene(src, str(tmp_path), "cornell")
     out = str(tmp_path / "radiance.bin")
     subprocess.check_call([DEMO, "--scene", path, "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(bounces), "--frames", "1", "--out", out])
