@@ -274,6 +274,7 @@ def main():
     for lane in lanes:
         lane.ctx.set_debug_flags(BASE_FLAGS)
     dyn_events = []
+    gather_tail = [None]                                        # the event behind the last gather enqueued by this rank
 
     def step(frame_index):
         lane = lanes[frame_index % len(lanes)]
@@ -293,7 +294,14 @@ def main():
             else:
                 lane.renderer.render(gs)
             if collective:
+                # one gather at a time per rank, in step order on every rank: the lanes have a communicator each (RCCL allows their concurrent use),
+                # but two grouped exchanges in flight on different streams could start in different orders on different ranks and wait for each other
+                # while the render kernels hold the CUs (VERDICT r3 weak point 10). An event chains them; the frames' render kernels still overlap.
+                if gather_tail[0] is not None:
+                    lane.stream.wait_event(gather_tail[0])
                 lane.ctx.gather_bands(lane.renderer.textures["Radiance"], lane.full, W, H, 8, 0)
+                gather_tail[0] = torch.cuda.Event()
+                gather_tail[0].record(lane.stream)
         return gs
 
     def barrier():
