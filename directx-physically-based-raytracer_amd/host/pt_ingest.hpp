@@ -563,17 +563,19 @@ inline std::vector<std::shared_ptr<MeshNode>> load_model(const std::string& path
         if ((int)prim.number("mode", 4) != 4 || !prim.has("attributes") || !prim.at("attributes").has("POSITION") || !prim.has("indices")) return false;   // :150-152,169-171,191-193
         const Json& attrs = prim.at("attributes");
         const Asset::Accessor pa = asset.accessor((size_t)attrs.at("POSITION").num);
+        if (pa.ncomp < 3) throw std::runtime_error("glTF: POSITION is not a VEC3");
         std::vector<std::array<float, 3>> pos(pa.count);
         for (size_t i = 0; i < pa.count; i++) for (int k = 0; k < 3; k++) pos[i][k] = (float)Asset::element(pa, i, k);
         const Asset::Accessor ia = asset.accessor((size_t)prim.at("indices").num);
         std::vector<uint32_t> idx(ia.count);
-        for (size_t i = 0; i < ia.count; i++) idx[i] = (uint32_t)Asset::element(ia, i, 0);
+        for (size_t i = 0; i < ia.count; i++) { idx[i] = (uint32_t)Asset::element(ia, i, 0); if (idx[i] >= pa.count) throw std::runtime_error("glTF: vertex index beyond the POSITION accessor"); }
         if (flipWindingOrder) for (size_t i = 0; i < idx.size() / 2; i++) std::swap(idx[i], idx[idx.size() - 1 - i]);        // slot count-1-i <- index i (:179)
         std::vector<std::array<float, 2>> uv[2];
         for (int s = 0; s < 2; s++) {
             const std::string name = "TEXCOORD_" + std::to_string(s);
             if (!attrs.has(name)) continue;
             const Asset::Accessor ua = asset.accessor((size_t)attrs.at(name).num);
+            if (ua.count != pa.count || ua.ncomp < 2) throw std::runtime_error("glTF: " + name + " does not match POSITION");
             uv[s].resize(ua.count);
             for (size_t i = 0; i < ua.count; i++) for (int k = 0; k < 2; k++) uv[s][i][k] = (float)Asset::element(ua, i, k);
             mesh.HasUV[s] = true;
@@ -581,6 +583,7 @@ inline std::vector<std::shared_ptr<MeshNode>> load_model(const std::string& path
         std::vector<std::array<float, 3>> nrm; std::vector<std::array<double, 3>> tan;
         if (attrs.has("NORMAL")) {
             const Asset::Accessor na = asset.accessor((size_t)attrs.at("NORMAL").num);
+            if (na.count != pa.count || na.ncomp < 3) throw std::runtime_error("glTF: NORMAL does not match POSITION");
             nrm.resize(na.count);
             for (size_t i = 0; i < na.count; i++) for (int k = 0; k < 3; k++) nrm[i][k] = (float)Asset::element(na, i, k);
             mesh.HasNormals = true;
